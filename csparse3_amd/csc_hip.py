@@ -1,0 +1,322 @@
+"""ctypes binding of libcsparse3_hip.so -- the MI355X factor/solve kernels behind
+the reference's flat-array calling convention.
+
+Every function takes and returns what a kernel module of the reference does
+(/root/reference/src/CSparse3/csc_numba.py): scalars int64, index arrays int32,
+values float64, matrices as loose (m, n, Ap, Ai, Ax) arguments, results as
+tuples of freshly allocated NumPy arrays, or in place for the solves.  The
+binding idiom is the reference author's own (research/mkl.py:3-5,33-35):
+ctypes.CDLL + ndarray.ctypes.data_as.
+
+There is no CPU fallback: if the shared library is missing or no GPU is
+visible the numeric entry points raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcsparse3_hip.so")
+
+CS3_LU, CS3_CHOLESKY = 0, 1
+ORDER_NATURAL, ORDER_AMD, ORDER_GIVEN = 0, 1, 2
+
+_i32p = C.POINTER(C.c_int32)
+_f64p = C.POINTER(C.c_double)
+I64 = C.c_int64
+
+
+class Cs3Info(C.Structure):
+    _fields_ = [("n", C.c_int64), ("nnz_a", C.c_int64), ("nnz_l", C.c_int64), ("nnz_u", C.c_int64),
+                ("nsuper", C.c_int64), ("nlevels", C.c_int64), ("max_front", C.c_int64),
+                ("max_width", C.c_int64), ("factor_bytes", C.c_int64), ("update_bytes", C.c_int64),
+                ("batch", C.c_int64), ("fail_col", C.c_int64), ("flops_factor", C.c_double),
+                ("t_order_s", C.c_double), ("t_symbolic_s", C.c_double)]
+
+
+class Cs3Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("cs3 error %d: %s" % (code, msg))
+        self.code = code
+
+
+class SingularMatrix(Cs3Error, ArithmeticError):
+    """A static diagonal pivot was zero, non-finite or rejected by tol (CS3_ERR_PIVOT)."""
+
+
+class NotPositiveDefinite(Cs3Error, ArithmeticError):
+    """Cholesky met a non-positive pivot (CS3_ERR_NOT_SPD)."""
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library; fail loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C csparse3_amd/csrc` -- there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.cs3_last_error.restype = C.c_char_p
+        vp = C.c_void_p
+        L.cs3_analyze.argtypes = [I64, I64, I64, _i32p, _i32p, _i32p, I64, C.POINTER(vp)]
+        L.cs3_free.argtypes = [vp]
+        L.cs3_get_info.argtypes = [vp, C.POINTER(Cs3Info)]
+        L.cs3_get_ordering.argtypes = [vp] + [_i32p] * 6
+        L.cs3_get_supernodes.argtypes = [vp] + [_i32p] * 3
+        L.cs3_factor.argtypes = [vp, _f64p, C.c_double]
+        L.cs3_factor_dev.argtypes = [vp, vp, C.c_double, vp]
+        L.cs3_factor_status.argtypes = [vp, vp]
+        L.cs3_solve.argtypes = [vp, _f64p, I64]
+        for f in (L.cs3_solve_dev, L.cs3_lsolve_dev, L.cs3_usolve_dev):
+            f.argtypes = [vp, vp, I64, vp]
+        L.cs3_get_factors.argtypes = [vp, I64, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p]
+        L.cs3_amd.argtypes = [I64, I64, I64, _i32p, _i32p, _i32p]
+        L.cs3_etree.argtypes = [I64, _i32p, _i32p, _i32p]
+        L.cs3_post.argtypes = [I64, _i32p, _i32p]
+        L.cs3_counts.argtypes = [I64, _i32p, _i32p, _i32p, _i32p, _i32p]
+        L.cs3_csc_lsolve.argtypes = [I64, _i32p, _i32p, _f64p, _f64p, I64]
+        L.cs3_csc_usolve.argtypes = [I64, _i32p, _i32p, _f64p, _f64p, I64]
+        L.cs3_csc_matvec.argtypes = [I64, I64, _i32p, _i32p, _f64p, _f64p, _f64p, I64]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc == 0:
+        return
+    msg = lib().cs3_last_error().decode("utf-8", "replace")
+    if rc == -4:
+        raise SingularMatrix(rc, msg)
+    if rc == -5:
+        raise NotPositiveDefinite(rc, msg)
+    raise Cs3Error(rc, msg)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _pi(a):
+    return None if a is None else a.ctypes.data_as(_i32p)
+
+
+def _pf(a):
+    return None if a is None else a.ctypes.data_as(_f64p)
+
+
+def device_count():
+    return int(lib().cs3_device_count())
+
+
+# ------------------------------------------------------ ordering / symbolic --
+
+def csc_amd_f(order, m, n, Ap, Ai):
+    """q = amd(A + A') (order 1) or the natural order (order 0)."""
+    Ap, Ai = _i32(Ap), _i32(Ai)
+    q = np.empty(n, dtype=np.int32)
+    _check(lib().cs3_amd(order, m, n, _pi(Ap), _pi(Ai), _pi(q)))
+    return q
+
+
+def csc_etree_f(n, Ap, Ai):
+    """Elimination tree of the symmetric matrix whose UPPER triangle is (Ap, Ai)."""
+    Ap, Ai = _i32(Ap), _i32(Ai)
+    parent = np.empty(n, dtype=np.int32)
+    _check(lib().cs3_etree(n, _pi(Ap), _pi(Ai), _pi(parent)))
+    return parent
+
+
+def csc_post_f(n, parent):
+    parent = _i32(parent)
+    post = np.empty(n, dtype=np.int32)
+    _check(lib().cs3_post(n, _pi(parent), _pi(post)))
+    return post
+
+
+def csc_counts_f(n, Ap, Ai, parent, post):
+    Ap, Ai, parent, post = _i32(Ap), _i32(Ai), _i32(parent), _i32(post)
+    cc = np.empty(n, dtype=np.int32)
+    _check(lib().cs3_counts(n, _pi(Ap), _pi(Ai), _pi(parent), _pi(post), _pi(cc)))
+    return cc
+
+
+# ------------------------------------------------------------------ handle --
+
+class Factorization:
+    """Device-resident factorisation handle: analyze once, (re)factor, solve.
+
+    kind: CS3_LU or CS3_CHOLESKY.  order: ORDER_NATURAL / ORDER_AMD, or pass q.
+    batch: number of matrices sharing the pattern (values [batch, nnz]).
+    """
+
+    def __init__(self, m, n, Ap, Ai, kind=CS3_LU, order=ORDER_AMD, q=None, batch=1):
+        assert m == n, "square matrix required"
+        self._h = C.c_void_p()
+        self.kind = kind
+        self.n = int(n)
+        self.batch = int(batch)
+        Ap, Ai = _i32(Ap), _i32(Ai)
+        self.nnz = int(Ap[n])
+        qa = None
+        if q is not None:
+            qa = _i32(q)
+            order = ORDER_GIVEN
+        _check(lib().cs3_analyze(kind, order, n, _pi(Ap), _pi(Ai), _pi(qa), batch, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().cs3_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def info(self):
+        out = Cs3Info()
+        _check(lib().cs3_get_info(self._h, C.byref(out)))
+        return out
+
+    def ordering(self):
+        """-> dict(q_amd, parent, post, colcount, q, pinv), all int32[n]."""
+        names = ("q_amd", "parent", "post", "colcount", "q", "pinv")
+        arrs = [np.empty(self.n, dtype=np.int32) for _ in names]
+        _check(lib().cs3_get_ordering(self._h, *[_pi(a) for a in arrs]))
+        return dict(zip(names, arrs))
+
+    def supernodes(self):
+        ns = int(self.info.nsuper)
+        sn_ptr = np.empty(ns + 1, dtype=np.int32)
+        sn_parent = np.empty(ns, dtype=np.int32)
+        sn_level = np.empty(ns, dtype=np.int32)
+        _check(lib().cs3_get_supernodes(self._h, _pi(sn_ptr), _pi(sn_parent), _pi(sn_level)))
+        return sn_ptr, sn_parent, sn_level
+
+    # -- numeric, host arrays
+    def factor(self, Ax, tol=0.0):
+        Ax = _f64(Ax)
+        assert Ax.size >= self.batch * self.nnz
+        _check(lib().cs3_factor(self._h, _pf(Ax), tol))
+        return self
+
+    def solve(self, b):
+        """Solve A x = b.  b: [n], [n, k] or [batch, n, k]; returns a new array."""
+        x = np.array(b, dtype=np.float64, order="C", copy=True)
+        per = self.batch * self.n
+        assert x.size % per == 0, "right-hand side does not match [batch,] n [, k]"
+        _check(lib().cs3_solve(self._h, _pf(x), x.size // per))
+        return x
+
+    # -- numeric, device pointers (e.g. torch.Tensor.data_ptr()) on a HIP stream
+    def factor_dev(self, ax_ptr, tol=0.0, stream=0):
+        _check(lib().cs3_factor_dev(self._h, C.c_void_p(ax_ptr), tol, C.c_void_p(stream)))
+
+    def factor_status(self, stream=0):
+        _check(lib().cs3_factor_status(self._h, C.c_void_p(stream)))
+
+    def solve_dev(self, x_ptr, k=1, stream=0):
+        _check(lib().cs3_solve_dev(self._h, C.c_void_p(x_ptr), k, C.c_void_p(stream)))
+
+    def lsolve_dev(self, x_ptr, k=1, stream=0):
+        _check(lib().cs3_lsolve_dev(self._h, C.c_void_p(x_ptr), k, C.c_void_p(stream)))
+
+    def usolve_dev(self, x_ptr, k=1, stream=0):
+        _check(lib().cs3_usolve_dev(self._h, C.c_void_p(x_ptr), k, C.c_void_p(stream)))
+
+    def factors(self, b=0, values=True):
+        """-> (Lp, Li, Lx, Up, Ui, Ux) in CSparse form (U parts None for Cholesky)."""
+        inf = self.info
+        n = self.n
+        Lp = np.empty(n + 1, dtype=np.int32)
+        Li = np.empty(inf.nnz_l, dtype=np.int32)
+        Lx = np.empty(inf.nnz_l, dtype=np.float64) if values else None
+        if self.kind == CS3_LU:
+            Up = np.empty(n + 1, dtype=np.int32)
+            Ui = np.empty(inf.nnz_u, dtype=np.int32)
+            Ux = np.empty(inf.nnz_u, dtype=np.float64) if values else None
+        else:
+            Up = Ui = Ux = None
+        _check(lib().cs3_get_factors(self._h, b, _pi(Lp), _pi(Li), _pf(Lx), _pi(Up), _pi(Ui), _pf(Ux)))
+        return Lp, Li, Lx, Up, Ui, Ux
+
+
+# ---------------------------------------------- flat functions, reference style --
+
+def csc_lu_f(m, n, Ap, Ai, Ax, tol=0.0, order=ORDER_AMD, q=None):
+    """LU with static diagonal pivots in a fill-reducing order: P A Q = L U.
+
+    -> (Lp, Li, Lx, Up, Ui, Ux, pinv, q).  L unit lower with the diagonal
+    first in each column, U upper with the diagonal last (cs_lu's layout).
+    """
+    with Factorization(m, n, Ap, Ai, CS3_LU, order, q) as F:
+        F.factor(Ax, tol)
+        Lp, Li, Lx, Up, Ui, Ux = F.factors()
+        o = F.ordering()
+    return Lp, Li, Lx, Up, Ui, Ux, o["pinv"], o["q"]
+
+
+def csc_chol_f(m, n, Ap, Ai, Ax, order=ORDER_AMD, q=None):
+    """Cholesky P A P' = L L'.  -> (Lp, Li, Lx, pinv)."""
+    with Factorization(m, n, Ap, Ai, CS3_CHOLESKY, order, q) as F:
+        F.factor(Ax)
+        Lp, Li, Lx, _, _, _ = F.factors()
+        o = F.ordering()
+    return Lp, Li, Lx, o["pinv"]
+
+
+def _tri(fn, n, Gp, Gi, Gx, x):
+    Gp, Gi, Gx = _i32(Gp), _i32(Gi), _f64(Gx)
+    assert isinstance(x, np.ndarray) and x.dtype == np.float64 and x.flags.c_contiguous
+    assert x.shape[0] == n
+    k = 1 if x.ndim == 1 else x.shape[1]
+    _check(fn(n, _pi(Gp), _pi(Gi), _pf(Gx), _pf(x), k))
+
+
+def csc_lsolve_f(n, Lp, Li, Lx, x):
+    """x = L \\ x in place; L lower triangular CSC, diagonal first per column."""
+    _tri(lib().cs3_csc_lsolve, n, Lp, Li, Lx, x)
+
+
+def csc_usolve_f(n, Up, Ui, Ux, x):
+    """x = U \\ x in place; U upper triangular CSC, diagonal last per column."""
+    _tri(lib().cs3_csc_usolve, n, Up, Ui, Ux, x)
+
+
+def csc_lusol_f(order, m, n, Ap, Ai, Ax, b, tol=0.0):
+    """x = A \\ b by LU (cs_lusol)."""
+    with Factorization(m, n, Ap, Ai, CS3_LU, order) as F:
+        return F.factor(Ax, tol).solve(b)
+
+
+def csc_cholsol_f(order, m, n, Ap, Ai, Ax, b):
+    """x = A \\ b by Cholesky (cs_cholsol)."""
+    with Factorization(m, n, Ap, Ai, CS3_CHOLESKY, order) as F:
+        return F.factor(Ax).solve(b)
+
+
+def csc_mat_vec_ff(m, n, Ap, Ai, Ax, x):
+    """y = A x on the device (csc_numba.py:309-328); x [n] or [n, k] row-major."""
+    Ap, Ai, Ax, x = _i32(Ap), _i32(Ai), _f64(Ax), _f64(x)
+    assert x.shape[0] == n
+    k = 1 if x.ndim == 1 else x.shape[1]
+    y = np.empty((m,) if x.ndim == 1 else (m, k), dtype=np.float64)
+    _check(lib().cs3_csc_matvec(m, n, _pi(Ap), _pi(Ai), _pf(Ax), _pf(x), _pf(y), k))
+    return y

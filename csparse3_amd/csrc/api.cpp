@@ -1,0 +1,547 @@
+// C ABI of the library (include/csparse3_amd.h): handle management, HBM
+// residency, hipGraph capture of the level schedules, host <-> device copies.
+#include <hip/hip_runtime_api.h>
+
+#include <climits>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+
+#include "cs3_device.hpp"
+
+using namespace cs3;
+
+namespace {
+thread_local std::string g_error;
+}
+
+namespace cs3 {
+void set_error(const std::string &msg) { g_error = msg; }
+}
+
+#define CS3_HIP(call)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            set_error(std::string(#call) + ": " + hipGetErrorString(e_));               \
+            return CS3_ERR_HIP;                                                         \
+        }                                                                               \
+    } while (0)
+
+struct cs3_handle_s {
+    Symbolic S;
+    DeviceFactor D;
+    long long batch = 1;
+    bool on_device = false, factored = false;
+    bool use_graph = true;
+    hipStream_t cap_stream = nullptr;
+    hipGraphExec_t factor_graph = nullptr;
+    double factor_graph_inv_tol = 0.0;
+    std::map<int, hipGraphExec_t> solve_graphs;   // keyed by nrhs
+    double *d_ax = nullptr;                       // staging for the host-pointer entry points
+    i64 *d_lmap = nullptr, *d_umap = nullptr;
+    double *d_lx = nullptr, *d_ux = nullptr;
+    long long fail_col = -1;
+};
+
+namespace {
+
+template <class T>
+int upload(T **dst, const std::vector<T> &src)
+{
+    size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    CS3_HIP(hipMalloc((void **) dst, bytes));
+    if (!src.empty()) CS3_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return CS3_OK;
+}
+
+void drop_solve_graphs(cs3_handle h)
+{
+    for (auto &kv : h->solve_graphs) (void) hipGraphExecDestroy(kv.second);
+    h->solve_graphs.clear();
+}
+
+int ensure_device(cs3_handle h)
+{
+    if (h->on_device) return CS3_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device visible: the numeric path runs on the GPU only (there is no CPU fallback)");
+        return CS3_ERR_HIP;
+    }
+    CS3_HIP(prepare_kernels());
+    const Symbolic &S = h->S;
+    DeviceFactor &D = h->D;
+    D.kind = S.kind; D.n = S.n; D.nnz_a = S.nnzA; D.batch = h->batch;
+    D.vals_size = S.vals_size; D.cb_size = S.cb_size; D.cv_size = S.cv_size;
+
+    std::vector<FrontMeta> meta(S.nsuper);
+    for (i32 s = 0; s < S.nsuper; ++s) {
+        FrontMeta &m = meta[s];
+        m.lpan = S.lpan_off[s]; m.upan = S.upan_off[s]; m.cb = S.cb_off[s]; m.cv = S.cv_off[s];
+        m.rel = S.rel_ptr[s]; m.st = S.st_ptr[s];
+        m.c0 = S.sn_ptr[s];
+        m.r = (int) (S.st_ptr[s + 1] - S.st_ptr[s]);
+        m.w = S.sn_ptr[s + 1] - S.sn_ptr[s];
+        m.child_begin = S.child_ptr[s]; m.child_end = S.child_ptr[s + 1];
+        m.parent = S.sn_parent[s];
+    }
+    std::vector<int> vsrc(S.vals_size, -1);
+    for (i64 p = 0; p < S.nnzA; ++p)
+        if (S.amap[p] >= 0) vsrc[S.amap[p]] = (int) p;
+    int rc;
+    if ((rc = upload(&D.meta, meta))) return rc;
+    if ((rc = upload(&D.sched, S.sched))) return rc;
+    if ((rc = upload(&D.child_idx, S.child_idx))) return rc;
+    if ((rc = upload(&D.rel_idx, S.rel_idx))) return rc;
+    if ((rc = upload(&D.st_idx, S.st_idx))) return rc;
+    if ((rc = upload(&D.vsrc, vsrc))) return rc;
+    if ((rc = upload(&D.q, S.q))) return rc;
+    CS3_HIP(hipMalloc((void **) &D.vals, std::max<size_t>(1, (size_t) (D.batch * D.vals_size)) * sizeof(double)));
+    CS3_HIP(hipMalloc((void **) &D.cb, std::max<size_t>(1, (size_t) (D.batch * D.cb_size)) * sizeof(double)));
+    CS3_HIP(hipMalloc((void **) &D.status, sizeof(int)));
+    CS3_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+    const char *ng = std::getenv("CS3_NO_GRAPH");
+    h->use_graph = !(ng && ng[0] == '1');
+    h->on_device = true;
+    return CS3_OK;
+}
+
+int ensure_rhs_capacity(cs3_handle h, long long nrhs)
+{
+    DeviceFactor &D = h->D;
+    if (nrhs <= D.nrhs_cap) return CS3_OK;
+    CS3_HIP(hipDeviceSynchronize());
+    drop_solve_graphs(h);
+    if (D.cv) (void) hipFree(D.cv);
+    if (D.xp) (void) hipFree(D.xp);
+    D.cv = D.xp = nullptr;
+    CS3_HIP(hipMalloc((void **) &D.cv, std::max<size_t>(1, (size_t) (D.batch * D.cv_size * nrhs)) * sizeof(double)));
+    CS3_HIP(hipMalloc((void **) &D.xp, std::max<size_t>(1, (size_t) (D.batch * D.n * nrhs)) * sizeof(double)));
+    D.nrhs_cap = nrhs;
+    return CS3_OK;
+}
+
+// Capture `body` (kernel launches on h->cap_stream) into an executable graph.
+template <class Body>
+int capture(cs3_handle h, hipGraphExec_t *exec, Body body)
+{
+    hipGraph_t graph = nullptr;
+    CS3_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+    hipError_t e = body(h->cap_stream);
+    hipError_t e2 = hipStreamEndCapture(h->cap_stream, &graph);
+    if (e != hipSuccess) { if (graph) (void) hipGraphDestroy(graph); CS3_HIP(e); }
+    CS3_HIP(e2);
+    hipError_t e3 = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
+    (void) hipGraphDestroy(graph);
+    CS3_HIP(e3);
+    return CS3_OK;
+}
+
+int run_factor(cs3_handle h, const double *ax_dev, double tol, hipStream_t st)
+{
+    DeviceFactor &D = h->D;
+    const double inv_tol = (tol > 0.0) ? 1.0 / tol : HUGE_VAL;
+    CS3_HIP(hipMemsetAsync(D.status, 0x7f, sizeof(int), st));   // 0x7f7f7f7f = clean
+    CS3_HIP(launch_assemble(D, ax_dev, st));
+    if (h->use_graph) {
+        if (h->factor_graph && h->factor_graph_inv_tol != inv_tol) {
+            (void) hipGraphExecDestroy(h->factor_graph);
+            h->factor_graph = nullptr;
+        }
+        if (!h->factor_graph) {
+            int rc = capture(h, &h->factor_graph, [&](hipStream_t cs) {
+                return launch_factor_levels(D, h->S.groups, inv_tol, cs);
+            });
+            if (rc) return rc;
+            h->factor_graph_inv_tol = inv_tol;
+        }
+        CS3_HIP(hipGraphLaunch(h->factor_graph, st));
+    } else {
+        CS3_HIP(launch_factor_levels(D, h->S.groups, inv_tol, st));
+    }
+    h->factored = true;
+    return CS3_OK;
+}
+
+int read_status(cs3_handle h, hipStream_t st)
+{
+    int col = 0;
+    CS3_HIP(hipMemcpyAsync(&col, h->D.status, sizeof(int), hipMemcpyDeviceToHost, st));
+    CS3_HIP(hipStreamSynchronize(st));
+    if (col == 0x7f7f7f7f) { h->fail_col = -1; return CS3_OK; }
+    h->fail_col = col;
+    h->factored = false;
+    if (h->S.kind == CS3_LU) {
+        set_error("static diagonal pivot rejected (zero, non-finite or below tol) at pivot column " +
+                  std::to_string(col));
+        return CS3_ERR_PIVOT;
+    }
+    set_error("matrix is not positive definite at pivot column " + std::to_string(col));
+    return CS3_ERR_NOT_SPD;
+}
+
+// mode 0: full solve with permutations; 1: lsolve only; 2: usolve only (in pivot order, on X itself)
+int run_solve(cs3_handle h, double *x_dev, long long k, int mode, hipStream_t st)
+{
+    if (!h->factored) { set_error("solve before a successful factorisation"); return CS3_ERR_STATE; }
+    if (k < 1 || k > INT_MAX) { set_error("solve: bad number of right-hand sides"); return CS3_ERR_ARG; }
+    int rc = ensure_rhs_capacity(h, k);
+    if (rc) return rc;
+    DeviceFactor &D = h->D;
+    const int nrhs = (int) k;
+    if (mode == 0) {
+        CS3_HIP(launch_permute(D, x_dev, D.xp, nrhs, false, st));
+        if (h->use_graph) {
+            auto it = h->solve_graphs.find(nrhs);
+            if (it == h->solve_graphs.end()) {
+                hipGraphExec_t exec = nullptr;
+                rc = capture(h, &exec, [&](hipStream_t cs) {
+                    hipError_t e = launch_solve_levels(D, h->S.groups, D.xp, nrhs, true, cs);
+                    if (e != hipSuccess) return e;
+                    return launch_solve_levels(D, h->S.groups, D.xp, nrhs, false, cs);
+                });
+                if (rc) return rc;
+                it = h->solve_graphs.emplace(nrhs, exec).first;
+            }
+            CS3_HIP(hipGraphLaunch(it->second, st));
+        } else {
+            CS3_HIP(launch_solve_levels(D, h->S.groups, D.xp, nrhs, true, st));
+            CS3_HIP(launch_solve_levels(D, h->S.groups, D.xp, nrhs, false, st));
+        }
+        CS3_HIP(launch_permute(D, D.xp, x_dev, nrhs, true, st));
+    } else {
+        CS3_HIP(launch_solve_levels(D, h->S.groups, x_dev, nrhs, mode == 1, st));
+    }
+    return CS3_OK;
+}
+
+int guard(cs3_handle h)
+{
+    if (!h) { set_error("null handle"); return CS3_ERR_ARG; }
+    return CS3_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *cs3_last_error(void) { return g_error.c_str(); }
+
+int cs3_version(void) { return 100; }
+
+int cs3_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int cs3_amd(int64_t order, int64_t m, int64_t n, const int32_t *Ap, const int32_t *Ai, int32_t *q)
+{
+    if (m != n || n < 0 || !Ap || !q) { set_error("cs3_amd: square pattern required"); return CS3_ERR_ARG; }
+    try {
+        if (order == CS3_ORDER_NATURAL) { for (int64_t k = 0; k < n; ++k) q[k] = (int32_t) k; return CS3_OK; }
+        if (order != CS3_ORDER_AMD) { set_error("cs3_amd: order must be 0 or 1"); return CS3_ERR_ARG; }
+        std::vector<i64> Cp, Ci;
+        symmetrized_pattern(n, Ap, Ai, Cp, Ci);
+        std::vector<i32> perm;
+        amd_order(n, Cp, Ci, perm);
+        std::memcpy(q, perm.data(), (size_t) n * sizeof(int32_t));
+    } catch (const std::exception &e) { set_error(e.what()); return CS3_ERR_ALLOC; }
+    return CS3_OK;
+}
+
+int cs3_etree(int64_t n, const int32_t *Ap, const int32_t *Ai, int32_t *parent)
+{
+    if (n < 0 || !Ap || !parent) { set_error("cs3_etree: null argument"); return CS3_ERR_ARG; }
+    try { etree_upper(n, Ap, Ai, parent); }
+    catch (const std::exception &e) { set_error(e.what()); return CS3_ERR_ALLOC; }
+    return CS3_OK;
+}
+
+int cs3_post(int64_t n, const int32_t *parent, int32_t *post)
+{
+    if (n < 0 || !parent || !post) { set_error("cs3_post: null argument"); return CS3_ERR_ARG; }
+    try { tree_postorder(n, parent, post); }
+    catch (const std::exception &e) { set_error(e.what()); return CS3_ERR_ALLOC; }
+    return CS3_OK;
+}
+
+int cs3_counts(int64_t n, const int32_t *Ap, const int32_t *Ai, const int32_t *parent,
+               const int32_t *post, int32_t *colcount)
+{
+    if (n < 0 || !Ap || !parent || !post || !colcount) { set_error("cs3_counts: null argument"); return CS3_ERR_ARG; }
+    try { cholesky_counts(n, Ap, Ai, parent, post, colcount); }
+    catch (const std::exception &e) { set_error(e.what()); return CS3_ERR_ALLOC; }
+    return CS3_OK;
+}
+
+int cs3_analyze(int64_t kind, int64_t order, int64_t n, const int32_t *Ap, const int32_t *Ai,
+                const int32_t *q_given, int64_t batch, cs3_handle *out)
+{
+    if (!out) { set_error("cs3_analyze: null output"); return CS3_ERR_ARG; }
+    *out = nullptr;
+    if (batch < 1) { set_error("cs3_analyze: batch must be >= 1"); return CS3_ERR_ARG; }
+    cs3_handle h = nullptr;
+    try {
+        h = new cs3_handle_s();
+        h->batch = batch;
+        analyze((int) kind, (int) order, n, Ap, Ai, q_given, h->S);
+    } catch (const std::bad_alloc &) {
+        delete h; set_error("cs3_analyze: out of memory"); return CS3_ERR_ALLOC;
+    } catch (const std::exception &e) {
+        delete h; set_error(e.what()); return CS3_ERR_ARG;
+    }
+    *out = h;
+    return CS3_OK;
+}
+
+int cs3_free(cs3_handle h)
+{
+    if (!h) return CS3_OK;
+    if (h->on_device) {
+        (void) hipDeviceSynchronize();
+        DeviceFactor &D = h->D;
+        if (h->factor_graph) (void) hipGraphExecDestroy(h->factor_graph);
+        drop_solve_graphs(h);
+        if (h->cap_stream) (void) hipStreamDestroy(h->cap_stream);
+        void *ptrs[] = {D.meta, D.sched, D.child_idx, D.rel_idx, D.st_idx, D.vsrc, D.q, D.vals, D.cb, D.cv,
+                        D.xp, D.status, h->d_ax, h->d_lmap, h->d_umap, h->d_lx, h->d_ux};
+        for (void *p : ptrs) if (p) (void) hipFree(p);
+    }
+    delete h;
+    return CS3_OK;
+}
+
+int cs3_get_info(cs3_handle h, cs3_info *info)
+{
+    int rc = guard(h); if (rc) return rc;
+    if (!info) { set_error("cs3_get_info: null output"); return CS3_ERR_ARG; }
+    const Symbolic &S = h->S;
+    info->n = S.n; info->nnz_a = S.nnzA;
+    info->nnz_l = S.Lp.empty() ? 0 : S.Lp[S.n];
+    info->nnz_u = (S.kind == CS3_LU && !S.Up.empty()) ? S.Up[S.n] : 0;
+    info->nsuper = S.nsuper; info->nlevels = S.nlevels;
+    info->max_front = S.max_front; info->max_width = S.max_width;
+    info->factor_bytes = S.vals_size * (int64_t) sizeof(double);
+    info->update_bytes = S.cb_size * (int64_t) sizeof(double);
+    info->batch = h->batch;
+    info->fail_col = h->fail_col;
+    info->flops_factor = S.flops;
+    info->t_order_s = S.t_order; info->t_symbolic_s = S.t_symbolic;
+    return CS3_OK;
+}
+
+int cs3_get_ordering(cs3_handle h, int32_t *q_amd, int32_t *parent, int32_t *post, int32_t *colcount,
+                     int32_t *q, int32_t *pinv)
+{
+    int rc = guard(h); if (rc) return rc;
+    const Symbolic &S = h->S;
+    const size_t bytes = (size_t) S.n * sizeof(int32_t);
+    if (q_amd) std::memcpy(q_amd, S.q_amd.data(), bytes);
+    if (parent) std::memcpy(parent, S.parent_amd.data(), bytes);
+    if (post) std::memcpy(post, S.post_amd.data(), bytes);
+    if (colcount) std::memcpy(colcount, S.count_amd.data(), bytes);
+    if (q) std::memcpy(q, S.q.data(), bytes);
+    if (pinv) std::memcpy(pinv, S.pinv.data(), bytes);
+    return CS3_OK;
+}
+
+int cs3_get_supernodes(cs3_handle h, int32_t *sn_ptr, int32_t *sn_parent, int32_t *sn_level)
+{
+    int rc = guard(h); if (rc) return rc;
+    const Symbolic &S = h->S;
+    if (sn_ptr) std::memcpy(sn_ptr, S.sn_ptr.data(), (size_t) (S.nsuper + 1) * sizeof(int32_t));
+    if (sn_parent) std::memcpy(sn_parent, S.sn_parent.data(), (size_t) S.nsuper * sizeof(int32_t));
+    if (sn_level) std::memcpy(sn_level, S.sn_level.data(), (size_t) S.nsuper * sizeof(int32_t));
+    return CS3_OK;
+}
+
+int cs3_factor_dev(cs3_handle h, const double *Ax_dev, double tol, void *stream)
+{
+    int rc = guard(h); if (rc) return rc;
+    if (!Ax_dev && h->S.nnzA > 0) { set_error("cs3_factor_dev: null values"); return CS3_ERR_ARG; }
+    if ((rc = ensure_device(h))) return rc;
+    return run_factor(h, Ax_dev, tol, (hipStream_t) stream);
+}
+
+int cs3_factor_status(cs3_handle h, void *stream)
+{
+    int rc = guard(h); if (rc) return rc;
+    if (!h->on_device) { set_error("cs3_factor_status: nothing factorised yet"); return CS3_ERR_STATE; }
+    return read_status(h, (hipStream_t) stream);
+}
+
+int cs3_factor(cs3_handle h, const double *Ax, double tol)
+{
+    int rc = guard(h); if (rc) return rc;
+    if (!Ax && h->S.nnzA > 0) { set_error("cs3_factor: null values"); return CS3_ERR_ARG; }
+    if ((rc = ensure_device(h))) return rc;
+    const size_t count = (size_t) (h->batch * h->S.nnzA);
+    if (!h->d_ax) CS3_HIP(hipMalloc((void **) &h->d_ax, std::max<size_t>(1, count) * sizeof(double)));
+    if (count) CS3_HIP(hipMemcpy(h->d_ax, Ax, count * sizeof(double), hipMemcpyHostToDevice));
+    if ((rc = run_factor(h, h->d_ax, tol, nullptr))) return rc;
+    return read_status(h, nullptr);
+}
+
+int cs3_solve_dev(cs3_handle h, double *X_dev, int64_t k, void *stream)
+{
+    int rc = guard(h); if (rc) return rc;
+    return run_solve(h, X_dev, k, 0, (hipStream_t) stream);
+}
+
+int cs3_lsolve_dev(cs3_handle h, double *X_dev, int64_t k, void *stream)
+{
+    int rc = guard(h); if (rc) return rc;
+    return run_solve(h, X_dev, k, 1, (hipStream_t) stream);
+}
+
+int cs3_usolve_dev(cs3_handle h, double *X_dev, int64_t k, void *stream)
+{
+    int rc = guard(h); if (rc) return rc;
+    return run_solve(h, X_dev, k, 2, (hipStream_t) stream);
+}
+
+int cs3_solve(cs3_handle h, double *X, int64_t k)
+{
+    int rc = guard(h); if (rc) return rc;
+    if (!X) { set_error("cs3_solve: null right-hand side"); return CS3_ERR_ARG; }
+    if (!h->factored) { set_error("solve before a successful factorisation"); return CS3_ERR_STATE; }
+    const size_t bytes = (size_t) (h->batch * h->S.n * k) * sizeof(double);
+    double *d_x = nullptr;
+    CS3_HIP(hipMalloc((void **) &d_x, std::max<size_t>(bytes, 8)));
+    hipError_t e = hipMemcpy(d_x, X, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = run_solve(h, d_x, k, 0, nullptr);
+        if (rc == CS3_OK) e = hipMemcpy(X, d_x, bytes, hipMemcpyDeviceToHost);
+    }
+    (void) hipFree(d_x);
+    if (rc) return rc;
+    CS3_HIP(e);
+    return CS3_OK;
+}
+
+int cs3_get_factors(cs3_handle h, int64_t b, int32_t *Lp, int32_t *Li, double *Lx,
+                    int32_t *Up, int32_t *Ui, double *Ux)
+{
+    int rc = guard(h); if (rc) return rc;
+    const Symbolic &S = h->S;
+    if (b < 0 || b >= h->batch) { set_error("cs3_get_factors: batch index out of range"); return CS3_ERR_ARG; }
+    if (S.kind == CS3_CHOLESKY && (Up || Ui || Ux)) { set_error("cs3_get_factors: Cholesky has no U"); return CS3_ERR_ARG; }
+    const i64 lnz = S.Lp[S.n];
+    if (Lp) std::memcpy(Lp, S.Lp.data(), (size_t) (S.n + 1) * sizeof(int32_t));
+    if (Li) std::memcpy(Li, S.Li.data(), (size_t) lnz * sizeof(int32_t));
+    const i64 unz = (S.kind == CS3_LU) ? S.Up[S.n] : 0;
+    if (Up) std::memcpy(Up, S.Up.data(), (size_t) (S.n + 1) * sizeof(int32_t));
+    if (Ui) std::memcpy(Ui, S.Ui.data(), (size_t) unz * sizeof(int32_t));
+    if (!Lx && !Ux) return CS3_OK;
+    if (!h->factored) { set_error("cs3_get_factors: values requested before a successful factorisation"); return CS3_ERR_STATE; }
+    const double *vals = h->D.vals + b * h->D.vals_size;
+    if (Lx) {
+        if (!h->d_lmap) { if ((rc = upload(&h->d_lmap, S.Lmap))) return rc; }
+        if (!h->d_lx) CS3_HIP(hipMalloc((void **) &h->d_lx, std::max<size_t>(1, (size_t) lnz) * sizeof(double)));
+        CS3_HIP(launch_extract(vals, (const long long *) h->d_lmap, h->d_lx, lnz, nullptr));
+        CS3_HIP(hipMemcpy(Lx, h->d_lx, (size_t) lnz * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    if (Ux) {
+        if (!h->d_umap) { if ((rc = upload(&h->d_umap, S.Umap))) return rc; }
+        if (!h->d_ux) CS3_HIP(hipMalloc((void **) &h->d_ux, std::max<size_t>(1, (size_t) unz) * sizeof(double)));
+        CS3_HIP(launch_extract(vals, (const long long *) h->d_umap, h->d_ux, unz, nullptr));
+        CS3_HIP(hipMemcpy(Ux, h->d_ux, (size_t) unz * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return CS3_OK;
+}
+
+static int csc_trisolve(int64_t n, const int32_t *Gp, const int32_t *Gi, const double *Gx, double *x,
+                        int64_t k, bool lower)
+{
+    if (n < 0 || k < 1 || k > INT_MAX || !Gp || !x) { set_error("triangular solve: bad argument"); return CS3_ERR_ARG; }
+    if (n == 0) return CS3_OK;
+    TriSchedule T;
+    try { tri_schedule(n, Gp, Gi, lower, T); }
+    catch (const std::bad_alloc &) { set_error("triangular solve: out of memory"); return CS3_ERR_ALLOC; }
+    catch (const std::exception &e) { set_error(e.what()); return CS3_ERR_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device visible: triangular solves run on the GPU only"); return CS3_ERR_HIP;
+    }
+    int *d_rows = nullptr, *d_rp = nullptr, *d_rj = nullptr;
+    long long *d_rmap = nullptr, *d_diag = nullptr;
+    double *d_gx = nullptr, *d_x = nullptr;
+    int rc = CS3_OK;
+    auto cleanup = [&]() {
+        void *ptrs[] = {d_rows, d_rp, d_rj, d_rmap, d_diag, d_gx, d_x};
+        for (void *p : ptrs) if (p) (void) hipFree(p);
+    };
+    std::vector<long long> rmap(T.Rmap.begin(), T.Rmap.end()), diag(T.diag.begin(), T.diag.end());
+    std::vector<double> gx(Gx, Gx + Gp[n]);
+    if ((rc = upload(&d_rows, T.level_rows)) || (rc = upload(&d_rp, T.Rp)) || (rc = upload(&d_rj, T.Rj)) ||
+        (rc = upload(&d_rmap, rmap)) || (rc = upload(&d_diag, diag)) || (rc = upload(&d_gx, gx))) {
+        cleanup(); return rc;
+    }
+    const size_t xbytes = (size_t) (n * k) * sizeof(double);
+    hipError_t e = hipMalloc((void **) &d_x, xbytes);
+    if (e == hipSuccess) e = hipMemcpy(d_x, x, xbytes, hipMemcpyHostToDevice);
+    for (i32 l = 0; l < T.nlevels && e == hipSuccess; ++l)
+        e = launch_tri_level(d_rows + T.level_ptr[l], T.level_ptr[l + 1] - T.level_ptr[l], d_rp, d_rj, d_rmap,
+                             d_diag, d_gx, d_x, (int) k, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(x, d_x, xbytes, hipMemcpyDeviceToHost);
+    cleanup();
+    CS3_HIP(e);
+    return CS3_OK;
+}
+
+int cs3_csc_lsolve(int64_t n, const int32_t *Lp, const int32_t *Li, const double *Lx, double *x, int64_t k)
+{
+    return csc_trisolve(n, Lp, Li, Lx, x, k, true);
+}
+
+int cs3_csc_usolve(int64_t n, const int32_t *Up, const int32_t *Ui, const double *Ux, double *x, int64_t k)
+{
+    return csc_trisolve(n, Up, Ui, Ux, x, k, false);
+}
+
+int cs3_csc_matvec(int64_t m, int64_t n, const int32_t *Ap, const int32_t *Ai, const double *Ax,
+                   const double *X, double *Y, int64_t k)
+{
+    if (m < 0 || n < 0 || k < 1 || k > INT_MAX || !Ap || !X || !Y) { set_error("cs3_csc_matvec: bad argument"); return CS3_ERR_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device visible: cs3_csc_matvec runs on the GPU only"); return CS3_ERR_HIP;
+    }
+    const i64 nnz = Ap[n];
+    // row view with ascending columns: the summation order of the column scatter loop
+    std::vector<int> Rp(m + 1, 0), Rj(nnz);
+    std::vector<double> Rx(nnz);
+    for (i64 p = 0; p < nnz; ++p) {
+        if (Ai[p] < 0 || Ai[p] >= m) { set_error("cs3_csc_matvec: row index out of range"); return CS3_ERR_ARG; }
+        ++Rp[Ai[p] + 1];
+    }
+    for (i64 i = 0; i < m; ++i) Rp[i + 1] += Rp[i];
+    {
+        std::vector<int> fill(Rp.begin(), Rp.end() - 1);
+        for (i64 j = 0; j < n; ++j)
+            for (i64 p = Ap[j]; p < Ap[j + 1]; ++p) { int q = fill[Ai[p]]++; Rj[q] = (int) j; Rx[q] = Ax[p]; }
+    }
+    int *d_rp = nullptr, *d_rj = nullptr;
+    double *d_rx = nullptr, *d_x = nullptr, *d_y = nullptr;
+    auto cleanup = [&]() {
+        void *ptrs[] = {d_rp, d_rj, d_rx, d_x, d_y};
+        for (void *p : ptrs) if (p) (void) hipFree(p);
+    };
+    int rc;
+    if ((rc = upload(&d_rp, Rp)) || (rc = upload(&d_rj, Rj)) || (rc = upload(&d_rx, Rx))) { cleanup(); return rc; }
+    hipError_t e = hipMalloc((void **) &d_x, std::max<size_t>(8, (size_t) (n * k) * sizeof(double)));
+    if (e == hipSuccess) e = hipMalloc((void **) &d_y, std::max<size_t>(8, (size_t) (m * k) * sizeof(double)));
+    if (e == hipSuccess) e = hipMemcpy(d_x, X, (size_t) (n * k) * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_matvec_rows(d_rp, d_rj, d_rx, d_x, d_y, m, (int) k, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(Y, d_y, (size_t) (m * k) * sizeof(double), hipMemcpyDeviceToHost);
+    cleanup();
+    CS3_HIP(e);
+    return CS3_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+// Internal declarations of the MI355X sparse direct-solve library.
+// Host side: ordering + symbolic analysis (C++).  Device side: kernels.hip.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/csparse3_amd.h"
+
+namespace cs3 {
+
+using i32 = int32_t;
+using i64 = int64_t;
+
+void set_error(const std::string &msg);
+
+// ---- ordering.cpp --------------------------------------------------------
+// Pattern of A + A' without the diagonal; column j lists A(:,j) in A's order
+// followed by the entries of A'(:,j) that A(:,j) lacks (A' has sorted columns).
+void symmetrized_pattern(i64 n, const i32 *Ap, const i32 *Ai,
+                         std::vector<i64> &Cp, std::vector<i64> &Ci);
+// Approximate minimum degree on that pattern.
+void amd_order(i64 n, const std::vector<i64> &Cp, const std::vector<i64> &Ci,
+               std::vector<i32> &perm);
+
+// ---- symbolic.cpp --------------------------------------------------------
+void etree_upper(i64 n, const i32 *Ap, const i32 *Ai, i32 *parent);
+void tree_postorder(i64 n, const i32 *parent, i32 *post);
+void cholesky_counts(i64 n, const i32 *Ap, const i32 *Ai, const i32 *parent,
+                     const i32 *post, i32 *colcount);
+
+// Size classes of fronts; each class is one kernel configuration.
+enum FrontClass : int { FC_R16 = 0, FC_R32 = 1, FC_R64 = 2, FC_LDS = 3, FC_BIG = 4, FC_COUNT = 5 };
+
+struct LaunchGroup {          // fronts of one level that share a kernel configuration
+    int level;
+    int cls;                  // FrontClass
+    i32 first, count;         // range in Symbolic::sched
+    i32 max_r;                // largest front order in the group (sizes dynamic LDS)
+};
+
+struct Symbolic {
+    i64 n = 0, nnzA = 0;
+    int kind = CS3_LU;
+    // ordering (original labels)
+    std::vector<i32> q_amd, parent_amd, post_amd, count_amd;
+    std::vector<i32> q, pinv;                 // pivot order used and its inverse
+    // postordered elimination tree
+    std::vector<i32> parent, colcount;
+    // supernodes
+    i32 nsuper = 0;
+    std::vector<i32> sn_ptr, col2sn, sn_parent, sn_level;
+    std::vector<i64> st_ptr;                  // [nsuper+1] into st_idx
+    std::vector<i32> st_idx;                  // sorted row structure; first w entries = own columns
+    std::vector<i32> child_ptr, child_idx;    // children of each supernode, ascending
+    std::vector<i64> lpan_off, upan_off, cb_off;   // per supernode, offsets in vals / cb pool / cv pool
+    std::vector<i64> cv_off;                  // contribution-vector offsets (forward solve)
+    std::vector<i64> rel_ptr;                 // [nsuper+1] into rel_idx (length r - w each)
+    std::vector<i32> rel_idx;                 // position of my update rows in the parent's structure
+    i64 vals_size = 0, cb_size = 0, cv_size = 0;
+    // schedule
+    i32 nlevels = 0;
+    std::vector<i32> sched;                   // supernode ids grouped by (level, class)
+    std::vector<LaunchGroup> groups;          // ascending level
+    // assembly of A into the panels: vals[amap[p]] += Ax[p]
+    std::vector<i64> amap;
+    // factors in CSC form
+    std::vector<i32> Lp, Li, Up, Ui;
+    std::vector<i64> Lmap, Umap;              // offsets in vals; -1 = constant 1.0 (unit diagonal)
+    i64 max_front = 0, max_width = 0;
+    double flops = 0.0;
+    double t_order = 0.0, t_symbolic = 0.0;
+};
+
+// Full analysis.  order: cs3_order.  Throws std::runtime_error on bad input.
+void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
+             const i32 *q_given, Symbolic &S);
+
+// Level schedule of a general triangular CSC matrix (cs3_csc_lsolve/usolve).
+struct TriSchedule {
+    i64 n = 0;
+    i32 nlevels = 0;
+    std::vector<i32> level_ptr, level_rows;   // rows grouped by level
+    std::vector<i32> Rp, Rj;                  // CSR of the strict triangle
+    std::vector<i64> Rmap;                    // CSR entry -> CSC entry
+    std::vector<i64> diag;                    // CSC entry of each diagonal
+};
+void tri_schedule(i64 n, const i32 *Gp, const i32 *Gi, bool lower, TriSchedule &T);
+
+}  // namespace cs3

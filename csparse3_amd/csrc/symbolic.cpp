@@ -1,0 +1,476 @@
+// Symbolic analysis: elimination tree, postorder, column counts, supernodes,
+// front structures, level schedule and every index map the device kernels use.
+//
+// Stands for cs_etree / cs_post / cs_counts / cs_schol / cs_sqr of the CSparse
+// lineage (Davis, "Direct Methods for Sparse Linear Systems", chapter 4); the
+// reference has none of them.  Data conventions follow
+// /root/reference/src/CSparse3/csc_numba.py: int32 indices, nnz = Ap[n],
+// rows inside a column in any order.
+#include <algorithm>
+#include <chrono>
+#include <numeric>
+#include <stdexcept>
+
+#include "cs3_internal.hpp"
+
+namespace cs3 {
+
+// ---------------------------------------------------------------- etree --
+// Liu's algorithm with path compression; (Ap, Ai) = upper triangle.
+void etree_upper(i64 n, const i32 *Ap, const i32 *Ai, i32 *parent)
+{
+    std::vector<i32> anc(n, -1);
+    for (i64 k = 0; k < n; ++k) {
+        parent[k] = -1;
+        for (i64 p = Ap[k]; p < Ap[k + 1]; ++p) {
+            for (i32 i = Ai[p]; i != -1 && i < k; ) {
+                i32 up = anc[i];
+                anc[i] = (i32) k;
+                if (up == -1) parent[i] = (i32) k;
+                i = up;
+            }
+        }
+    }
+}
+
+// children visited in ascending order; roots in ascending order
+void tree_postorder(i64 n, const i32 *parent, i32 *post)
+{
+    std::vector<i32> first(n, -1), sib(n, -1), stack;
+    for (i64 j = n - 1; j >= 0; --j) {
+        if (parent[j] < 0) continue;
+        sib[j] = first[parent[j]];
+        first[parent[j]] = (i32) j;
+    }
+    i64 k = 0;
+    for (i64 root = 0; root < n; ++root) {
+        if (parent[root] >= 0) continue;
+        stack.assign(1, (i32) root);
+        while (!stack.empty()) {
+            i32 v = stack.back();
+            i32 c = first[v];
+            if (c == -1) { stack.pop_back(); post[k++] = v; }
+            else { first[v] = sib[c]; stack.push_back(c); }
+        }
+    }
+}
+
+// Gilbert, Ng & Peyton: skeleton-matrix leaves + least common ancestors.
+void cholesky_counts(i64 n, const i32 *Ap, const i32 *Ai, const i32 *parent,
+                     const i32 *post, i32 *colcount)
+{
+    // row lists of the upper triangle = columns of its transpose
+    std::vector<i32> Tp(n + 1, 0), Ti(Ap[n]);
+    for (i64 p = 0; p < Ap[n]; ++p) ++Tp[Ai[p] + 1];
+    for (i64 j = 0; j < n; ++j) Tp[j + 1] += Tp[j];
+    {
+        std::vector<i32> fill(Tp.begin(), Tp.end() - 1);
+        for (i64 j = 0; j < n; ++j)
+            for (i64 p = Ap[j]; p < Ap[j + 1]; ++p) Ti[fill[Ai[p]]++] = (i32) j;
+    }
+    std::vector<i32> set(n), maxfirst(n, -1), prevleaf(n, -1), first(n, -1);
+    i32 *delta = colcount;
+    for (i64 k = 0; k < n; ++k) {
+        i32 j = post[k];
+        delta[j] = (first[j] == -1) ? 1 : 0;
+        for (; j != -1 && first[j] == -1; j = parent[j]) first[j] = (i32) k;
+    }
+    std::iota(set.begin(), set.end(), 0);
+    for (i64 k = 0; k < n; ++k) {
+        i32 j = post[k];
+        if (parent[j] != -1) --delta[parent[j]];
+        for (i64 p = Tp[j]; p < Tp[j + 1]; ++p) {
+            i32 i = Ti[p];
+            if (i <= j || first[j] <= maxfirst[i]) continue;   // j is not a leaf of row subtree i
+            maxfirst[i] = first[j];
+            i32 jprev = prevleaf[i];
+            prevleaf[i] = j;
+            ++delta[j];
+            if (jprev == -1) continue;                         // first leaf: no overlap yet
+            i32 q = jprev;
+            while (q != set[q]) q = set[q];
+            for (i32 s = jprev; s != q; ) { i32 sp = set[s]; set[s] = q; s = sp; }
+            --delta[q];
+        }
+        if (parent[j] != -1) set[j] = parent[j];
+    }
+    for (i64 j = 0; j < n; ++j)
+        if (parent[j] != -1) colcount[parent[j]] += colcount[j];
+}
+
+// ------------------------------------------------------------- analysis --
+namespace {
+
+double seconds_since(std::chrono::steady_clock::time_point t0)
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+int front_class(i64 r)
+{
+    if (r <= 16) return FC_R16;
+    if (r <= 32) return FC_R32;
+    if (r <= 64) return FC_R64;
+    if (r <= 136) return FC_LDS;      // 136*137*8 B = 149 KB of the 160 KB LDS
+    return FC_BIG;
+}
+
+}  // namespace
+
+void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
+             const i32 *q_given, Symbolic &S)
+{
+    if (n < 0 || !Ap || (n > 0 && !Ai && Ap[n] > 0)) throw std::runtime_error("analyze: null input");
+    if (kind != CS3_LU && kind != CS3_CHOLESKY) throw std::runtime_error("analyze: unknown kind");
+    if (n >= (i64) 1 << 30) throw std::runtime_error("analyze: n too large for int32 indices");
+    if (Ap[0] != 0) throw std::runtime_error("analyze: Ap[0] != 0");
+    for (i64 j = 0; j < n; ++j)
+        if (Ap[j + 1] < Ap[j]) throw std::runtime_error("analyze: Ap not monotone");
+    const i64 nnzA = n > 0 ? Ap[n] : 0;
+    for (i64 p = 0; p < nnzA; ++p)
+        if (Ai[p] < 0 || Ai[p] >= n) throw std::runtime_error("analyze: row index out of range");
+    {   // duplicates would make the assembly ambiguous (LilMat.to_csc cannot produce them)
+        std::vector<i64> seen(n, -1);
+        for (i64 j = 0; j < n; ++j)
+            for (i64 p = Ap[j]; p < Ap[j + 1]; ++p) {
+                if (seen[Ai[p]] == j) throw std::runtime_error("analyze: duplicate entry in a column");
+                seen[Ai[p]] = j;
+            }
+    }
+    S = Symbolic();
+    S.n = n; S.nnzA = nnzA; S.kind = kind;
+
+    // ---- 1. fill-reducing order on the pattern of A + A'
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<i64> Cp, Ci;
+    symmetrized_pattern(n, Ap, Ai, Cp, Ci);
+    S.q_amd.resize(n);
+    if (order == CS3_ORDER_NATURAL) {
+        std::iota(S.q_amd.begin(), S.q_amd.end(), 0);
+    } else if (order == CS3_ORDER_AMD) {
+        amd_order(n, Cp, Ci, S.q_amd);
+    } else if (order == CS3_ORDER_GIVEN) {
+        if (!q_given) throw std::runtime_error("analyze: CS3_ORDER_GIVEN without q");
+        std::vector<char> hit(n, 0);
+        for (i64 k = 0; k < n; ++k) {
+            i32 v = q_given[k];
+            if (v < 0 || v >= n || hit[v]) throw std::runtime_error("analyze: q is not a permutation");
+            hit[v] = 1;
+            S.q_amd[k] = v;
+        }
+    } else {
+        throw std::runtime_error("analyze: unknown order");
+    }
+    S.t_order = seconds_since(t0);
+    t0 = std::chrono::steady_clock::now();
+
+    // ---- 2. strict upper triangle of P (A + A') P' in the fill-reducing order
+    std::vector<i32> pinv0(n);
+    for (i64 k = 0; k < n; ++k) pinv0[S.q_amd[k]] = (i32) k;
+    std::vector<i32> Bp(n + 1, 0), Bi;
+    Bi.reserve(Ci.size() / 2 + 1);
+    for (i64 k = 0; k < n; ++k) {
+        i64 col = S.q_amd[k];
+        for (i64 p = Cp[col]; p < Cp[col + 1]; ++p) {
+            i32 i2 = pinv0[Ci[p]];
+            if (i2 < k) Bi.push_back(i2);
+        }
+        Bp[k + 1] = (i32) Bi.size();
+    }
+
+    // ---- 3. etree, postorder, column counts (labels: position in q_amd)
+    S.parent_amd.resize(n); S.post_amd.resize(n); S.count_amd.resize(n);
+    etree_upper(n, Bp.data(), Bi.data(), S.parent_amd.data());
+    tree_postorder(n, S.parent_amd.data(), S.post_amd.data());
+    cholesky_counts(n, Bp.data(), Bi.data(), S.parent_amd.data(), S.post_amd.data(),
+                    S.count_amd.data());
+
+    // ---- 4. pivot order = fill-reducing order composed with the postorder
+    S.q.resize(n); S.pinv.resize(n); S.parent.resize(n); S.colcount.resize(n);
+    std::vector<i32> newlab(n);
+    for (i64 k = 0; k < n; ++k) newlab[S.post_amd[k]] = (i32) k;
+    for (i64 k = 0; k < n; ++k) {
+        i32 old = S.post_amd[k];
+        S.q[k] = S.q_amd[old];
+        S.pinv[S.q[k]] = (i32) k;
+        S.parent[k] = S.parent_amd[old] < 0 ? -1 : newlab[S.parent_amd[old]];
+        S.colcount[k] = S.count_amd[old];
+    }
+
+    // ---- 5. supernodes: maximal runs j-1 -> j with parent[j-1] = j and
+    //         colcount[j] = colcount[j-1] - 1 (identical structure below the run)
+    S.col2sn.resize(n);
+    S.sn_ptr.clear();
+    for (i64 j = 0; j < n; ++j) {
+        bool join = j > 0 && S.parent[j - 1] == j && S.colcount[j] == S.colcount[j - 1] - 1;
+        if (!join) S.sn_ptr.push_back((i32) j);
+        S.col2sn[j] = (i32) S.sn_ptr.size() - 1;
+    }
+    S.nsuper = (i32) S.sn_ptr.size();
+    S.sn_ptr.push_back((i32) n);
+    const i32 ns = S.nsuper;
+    S.sn_parent.assign(ns, -1);
+    for (i32 s = 0; s < ns; ++s) {
+        i32 last = S.sn_ptr[s + 1] - 1;
+        if (S.parent[last] >= 0) S.sn_parent[s] = S.col2sn[S.parent[last]];
+    }
+    S.child_ptr.assign(ns + 1, 0);
+    for (i32 s = 0; s < ns; ++s) if (S.sn_parent[s] >= 0) ++S.child_ptr[S.sn_parent[s] + 1];
+    for (i32 s = 0; s < ns; ++s) S.child_ptr[s + 1] += S.child_ptr[s];
+    S.child_idx.resize(S.child_ptr[ns]);
+    {
+        std::vector<i32> fill(S.child_ptr.begin(), S.child_ptr.end() - 1);
+        for (i32 s = 0; s < ns; ++s)
+            if (S.sn_parent[s] >= 0) S.child_idx[fill[S.sn_parent[s]]++] = s;
+    }
+
+    // ---- 6. row structure of every front: own columns, then the sorted union of
+    //         A's entries below the supernode and the children's update rows
+    S.st_ptr.assign(ns + 1, 0);
+    for (i32 s = 0; s < ns; ++s) S.st_ptr[s + 1] = S.st_ptr[s] + S.colcount[S.sn_ptr[s]];
+    S.st_idx.resize(S.st_ptr[ns]);
+    {
+        std::vector<i32> mark(n, -1);
+        for (i32 s = 0; s < ns; ++s) {
+            const i32 c0 = S.sn_ptr[s], c1 = S.sn_ptr[s + 1], w = c1 - c0;
+            i32 *st = S.st_idx.data() + S.st_ptr[s];
+            const i64 r = S.st_ptr[s + 1] - S.st_ptr[s];
+            i64 cnt = 0;
+            for (i32 j = c0; j < c1; ++j) st[cnt++] = j;
+            for (i32 j = c0; j < c1; ++j) {
+                i64 col = S.q[j];
+                for (i64 p = Cp[col]; p < Cp[col + 1]; ++p) {
+                    i32 i2 = S.pinv[Ci[p]];
+                    if (i2 >= c1 && mark[i2] != s) {
+                        mark[i2] = s;
+                        if (cnt >= r) throw std::runtime_error("analyze: structure exceeds column count");
+                        st[cnt++] = i2;
+                    }
+                }
+            }
+            for (i32 cp = S.child_ptr[s]; cp < S.child_ptr[s + 1]; ++cp) {
+                i32 c = S.child_idx[cp];
+                i32 wc = S.sn_ptr[c + 1] - S.sn_ptr[c];
+                for (i64 p = S.st_ptr[c] + wc; p < S.st_ptr[c + 1]; ++p) {
+                    i32 i2 = S.st_idx[p];
+                    if (i2 >= c1 && mark[i2] != s) {
+                        mark[i2] = s;
+                        if (cnt >= r) throw std::runtime_error("analyze: structure exceeds column count");
+                        st[cnt++] = i2;
+                    }
+                }
+            }
+            if (cnt != r) throw std::runtime_error("analyze: structure does not match column count");
+            std::sort(st + w, st + r);
+        }
+    }
+
+    // ---- 7. storage offsets; child -> parent relative indices
+    S.lpan_off.assign(ns, 0); S.upan_off.assign(ns, 0); S.cb_off.assign(ns, 0); S.cv_off.assign(ns, 0);
+    S.rel_ptr.assign(ns + 1, 0);
+    i64 voff = 0, cboff = 0, cvoff = 0;
+    S.max_front = 0; S.max_width = 0; S.flops = 0.0;
+    for (i32 s = 0; s < ns; ++s) {
+        const i64 w = S.sn_ptr[s + 1] - S.sn_ptr[s];
+        const i64 r = S.st_ptr[s + 1] - S.st_ptr[s];
+        const i64 nb = r - w;
+        S.lpan_off[s] = voff; voff += r * w;
+        if (kind == CS3_LU) { S.upan_off[s] = voff; voff += nb * w; }
+        S.cb_off[s] = cboff; cboff += nb * nb;
+        S.cv_off[s] = cvoff; cvoff += nb;
+        S.rel_ptr[s + 1] = S.rel_ptr[s] + nb;
+        S.max_front = std::max(S.max_front, r);
+        S.max_width = std::max(S.max_width, w);
+        for (i64 k = 0; k < w; ++k) {
+            double m = (double) (r - k - 1);
+            S.flops += (kind == CS3_LU) ? (m + 2.0 * m * m) : (m + m * (m + 1.0) + 1.0);
+        }
+    }
+    S.vals_size = voff; S.cb_size = cboff; S.cv_size = cvoff;
+    S.rel_idx.resize(S.rel_ptr[ns]);
+    for (i32 s = 0; s < ns; ++s) {
+        i32 p = S.sn_parent[s];
+        if (p < 0) continue;
+        const i32 w = S.sn_ptr[s + 1] - S.sn_ptr[s];
+        const i32 *mine = S.st_idx.data() + S.st_ptr[s] + w;
+        const i64 nb = S.st_ptr[s + 1] - S.st_ptr[s] - w;
+        const i32 *theirs = S.st_idx.data() + S.st_ptr[p];
+        const i64 rp = S.st_ptr[p + 1] - S.st_ptr[p];
+        i32 *rel = S.rel_idx.data() + S.rel_ptr[s];
+        i64 t = 0;
+        for (i64 i = 0; i < nb; ++i) {
+            while (t < rp && theirs[t] < mine[i]) ++t;
+            if (t >= rp || theirs[t] != mine[i])
+                throw std::runtime_error("analyze: child structure not contained in parent");
+            rel[i] = (i32) t;
+        }
+    }
+
+    // ---- 8. levels (leaves = 0) and launch groups by (level, size class)
+    S.sn_level.assign(ns, 0);
+    for (i32 s = 0; s < ns; ++s) {          // children precede parents in postorder
+        i32 p = S.sn_parent[s];
+        if (p >= 0) S.sn_level[p] = std::max(S.sn_level[p], S.sn_level[s] + 1);
+    }
+    S.nlevels = 0;
+    for (i32 s = 0; s < ns; ++s) S.nlevels = std::max(S.nlevels, S.sn_level[s] + 1);
+    S.sched.resize(ns);
+    std::iota(S.sched.begin(), S.sched.end(), 0);
+    auto cls_of = [&](i32 s) { return front_class(S.st_ptr[s + 1] - S.st_ptr[s]); };
+    std::stable_sort(S.sched.begin(), S.sched.end(), [&](i32 a, i32 b) {
+        if (S.sn_level[a] != S.sn_level[b]) return S.sn_level[a] < S.sn_level[b];
+        return cls_of(a) < cls_of(b);
+    });
+    S.groups.clear();
+    for (i32 t = 0; t < ns; ) {
+        i32 s = S.sched[t];
+        LaunchGroup g{S.sn_level[s], cls_of(s), t, 0, 0};
+        while (t < ns && S.sn_level[S.sched[t]] == g.level && cls_of(S.sched[t]) == g.cls) {
+            g.max_r = std::max<i32>(g.max_r, (i32) (S.st_ptr[S.sched[t] + 1] - S.st_ptr[S.sched[t]]));
+            ++t;
+        }
+        g.count = t - g.first;
+        S.groups.push_back(g);
+    }
+
+    // ---- 9. where each entry of A lands in the panels
+    auto find_row = [&](i32 s, i32 row) -> i64 {
+        const i32 *st = S.st_idx.data() + S.st_ptr[s];
+        const i64 r = S.st_ptr[s + 1] - S.st_ptr[s];
+        const i32 *it = std::lower_bound(st, st + r, row);
+        if (it == st + r || *it != row) throw std::runtime_error("analyze: entry outside the symbolic structure");
+        return it - st;
+    };
+    S.amap.assign(nnzA, -1);
+    bool has_upper = false;
+    if (kind == CS3_CHOLESKY)
+        for (i64 j = 0; j < n && !has_upper; ++j)
+            for (i64 p = Ap[j]; p < Ap[j + 1]; ++p) if (Ai[p] < j) { has_upper = true; break; }
+    for (i64 jo = 0; jo < n; ++jo) {
+        for (i64 p = Ap[jo]; p < Ap[jo + 1]; ++p) {
+            i64 io = Ai[p];
+            i32 i2 = S.pinv[io], j2 = S.pinv[jo];
+            if (kind == CS3_CHOLESKY) {
+                // cs_chol reads the upper triangle of A; a lower-only input is mirrored
+                bool use = (io == jo) || (has_upper ? io < jo : io > jo);
+                if (!use) continue;
+                if (i2 < j2) std::swap(i2, j2);
+            }
+            if (i2 >= j2) {
+                i32 s = S.col2sn[j2];
+                i64 c0 = S.sn_ptr[s], r = S.st_ptr[s + 1] - S.st_ptr[s];
+                S.amap[p] = S.lpan_off[s] + find_row(s, i2) + (j2 - c0) * r;
+            } else {
+                i32 s = S.col2sn[i2];
+                i64 c0 = S.sn_ptr[s], c1 = S.sn_ptr[s + 1], w = c1 - c0;
+                i64 r = S.st_ptr[s + 1] - S.st_ptr[s];
+                if (j2 < c1) S.amap[p] = S.lpan_off[s] + (i2 - c0) + (j2 - c0) * r;
+                else S.amap[p] = S.upan_off[s] + (find_row(s, j2) - w) + (i2 - c0) * (r - w);
+            }
+        }
+    }
+
+    // ---- 10. factors in CSC form: L diagonal first, U diagonal last
+    S.Lp.assign(n + 1, 0);
+    for (i64 j = 0; j < n; ++j) S.Lp[j + 1] = S.Lp[j] + S.colcount[j];
+    S.Li.resize(S.Lp[n]); S.Lmap.resize(S.Lp[n]);
+    for (i32 s = 0; s < ns; ++s) {
+        const i64 c0 = S.sn_ptr[s], w = S.sn_ptr[s + 1] - c0;
+        const i64 r = S.st_ptr[s + 1] - S.st_ptr[s];
+        const i32 *st = S.st_idx.data() + S.st_ptr[s];
+        for (i64 jj = 0; jj < w; ++jj) {
+            i64 p = S.Lp[c0 + jj];
+            for (i64 i = jj; i < r; ++i, ++p) {
+                S.Li[p] = st[i];
+                S.Lmap[p] = (i == jj && kind == CS3_LU) ? -1 : S.lpan_off[s] + i + jj * r;
+            }
+        }
+    }
+    if (kind == CS3_LU) {
+        S.Up.assign(n + 1, 0);
+        for (i32 s = 0; s < ns; ++s) {
+            const i64 c0 = S.sn_ptr[s], w = S.sn_ptr[s + 1] - c0;
+            const i64 r = S.st_ptr[s + 1] - S.st_ptr[s];
+            const i32 *st = S.st_idx.data() + S.st_ptr[s];
+            for (i64 kk = 0; kk < w; ++kk)
+                for (i64 i = kk; i < r; ++i) ++S.Up[st[i] + 1];
+        }
+        for (i64 j = 0; j < n; ++j) S.Up[j + 1] += S.Up[j];
+        S.Ui.resize(S.Up[n]); S.Umap.resize(S.Up[n]);
+        std::vector<i32> fill(S.Up.begin(), S.Up.end() - 1);
+        for (i32 s = 0; s < ns; ++s) {          // pivot rows ascending => rows sorted, diagonal last
+            const i64 c0 = S.sn_ptr[s], w = S.sn_ptr[s + 1] - c0;
+            const i64 r = S.st_ptr[s + 1] - S.st_ptr[s], nb = r - w;
+            const i32 *st = S.st_idx.data() + S.st_ptr[s];
+            for (i64 kk = 0; kk < w; ++kk) {
+                for (i64 i = kk; i < r; ++i) {
+                    i32 p = fill[st[i]]++;
+                    S.Ui[p] = (i32) (c0 + kk);
+                    S.Umap[p] = (i < w) ? S.lpan_off[s] + kk + i * r
+                                        : S.upan_off[s] + (i - w) + kk * nb;
+                }
+            }
+        }
+    }
+    S.t_symbolic = seconds_since(t0);
+}
+
+// ----------------------------------------------- general triangular CSC --
+// Row-oriented level schedule: row i can be solved once every row j with
+// G(i,j) != 0 (j != i) is done; level = longest such chain.
+void tri_schedule(i64 n, const i32 *Gp, const i32 *Gi, bool lower, TriSchedule &T)
+{
+    T = TriSchedule();
+    T.n = n;
+    T.diag.assign(n, -1);
+    T.Rp.assign(n + 1, 0);
+    for (i64 j = 0; j < n; ++j) {
+        if (Gp[j + 1] <= Gp[j]) throw std::runtime_error("triangular solve: empty column");
+        i64 d = lower ? Gp[j] : Gp[j + 1] - 1;
+        if (Gi[d] != j) throw std::runtime_error("triangular solve: diagonal not first (L) / last (U)");
+        T.diag[j] = d;
+        for (i64 p = Gp[j]; p < Gp[j + 1]; ++p) {
+            if (p == d) continue;
+            i32 i = Gi[p];
+            if (i < 0 || i >= n || (lower ? i <= j : i >= j))
+                throw std::runtime_error("triangular solve: entry on the wrong side of the diagonal");
+            ++T.Rp[i + 1];
+        }
+    }
+    for (i64 i = 0; i < n; ++i) T.Rp[i + 1] += T.Rp[i];
+    T.Rj.resize(T.Rp[n]); T.Rmap.resize(T.Rp[n]);
+    {
+        std::vector<i32> fill(T.Rp.begin(), T.Rp.end() - 1);
+        for (i64 j = 0; j < n; ++j)
+            for (i64 p = Gp[j]; p < Gp[j + 1]; ++p) {
+                if (p == T.diag[j]) continue;
+                i32 q = fill[Gi[p]]++;
+                T.Rj[q] = (i32) j;
+                T.Rmap[q] = p;
+            }
+    }
+    std::vector<i32> level(n, 0);
+    i32 nlev = 0;
+    if (lower) {
+        for (i64 i = 0; i < n; ++i) {
+            i32 lv = 0;
+            for (i64 p = T.Rp[i]; p < T.Rp[i + 1]; ++p) lv = std::max(lv, level[T.Rj[p]] + 1);
+            level[i] = lv; nlev = std::max(nlev, lv + 1);
+        }
+    } else {
+        for (i64 i = n - 1; i >= 0; --i) {
+            i32 lv = 0;
+            for (i64 p = T.Rp[i]; p < T.Rp[i + 1]; ++p) lv = std::max(lv, level[T.Rj[p]] + 1);
+            level[i] = lv; nlev = std::max(nlev, lv + 1);
+        }
+    }
+    T.nlevels = nlev;
+    T.level_ptr.assign(nlev + 1, 0);
+    for (i64 i = 0; i < n; ++i) ++T.level_ptr[level[i] + 1];
+    for (i32 l = 0; l < nlev; ++l) T.level_ptr[l + 1] += T.level_ptr[l];
+    T.level_rows.resize(n);
+    std::vector<i32> fill(T.level_ptr.begin(), T.level_ptr.end() - 1);
+    for (i64 i = 0; i < n; ++i) T.level_rows[fill[level[i]]++] = (i32) i;
+}
+
+}  // namespace cs3

@@ -1,0 +1,149 @@
+/*
+ * csparse3_amd.h -- C ABI of the MI355X (gfx950) sparse direct-solve backend.
+ *
+ * This is the drop-in boundary for the factor/solve path of SanPen/CSparse3.
+ * The reference selects its kernel module by name at import
+ * (/root/reference/src/CSparse3/csc.py:29-41, __config__.NATIVE) and calls
+ * kernels with loose flat arrays: scalars int64, index arrays int32, values
+ * float64, matrices as (m, n, Ap, Ai, Ax)
+ * (/root/reference/src/CSparse3/csc_numba.py:183,331,400 signature strings).
+ * Every entry point below keeps that convention: plain pointers and sizes,
+ * no torch / numpy types.  The reference has no factor/solve kernel at this
+ * snapshot, so each function names the CSparse-lineage
+ * kernel it stands for and the reference convention it follows, not a line it
+ * replaces.  The ctypes binding a maintainer would add is in INTEGRATION.md.
+ *
+ * Return value: 0 on success, negative cs3_status otherwise;
+ * cs3_last_error() gives the message for the calling thread.
+ * Pointers named *_dev are device (HBM) addresses, everything else is host.
+ * `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * A handle may be used by one host thread at a time.
+ */
+#ifndef CSPARSE3_AMD_H
+#define CSPARSE3_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cs3_handle_s *cs3_handle;
+
+enum cs3_status {
+    CS3_OK = 0,
+    CS3_ERR_ARG = -1,        /* bad argument / shape (the reference asserts, csc_numba.py:240,322) */
+    CS3_ERR_ALLOC = -2,
+    CS3_ERR_HIP = -3,        /* HIP runtime error, no device, launch failure */
+    CS3_ERR_PIVOT = -4,      /* zero / rejected static pivot; column in cs3_info.fail_col */
+    CS3_ERR_NOT_SPD = -5,    /* non-positive Cholesky pivot; column in cs3_info.fail_col */
+    CS3_ERR_STATE = -6       /* call out of order (solve before factor ...) */
+};
+
+enum cs3_kind { CS3_LU = 0, CS3_CHOLESKY = 1 };
+enum cs3_order { CS3_ORDER_NATURAL = 0, CS3_ORDER_AMD = 1, CS3_ORDER_GIVEN = 2 };
+
+typedef struct cs3_info {
+    int64_t n, nnz_a;
+    int64_t nnz_l, nnz_u;          /* entries of L (incl. diagonal) and U (incl. diagonal) */
+    int64_t nsuper, nlevels;       /* supernodes, levels of the supernodal tree */
+    int64_t max_front, max_width;  /* largest front order r and supernode width w */
+    int64_t factor_bytes;          /* dense panel storage in HBM, bytes per matrix */
+    int64_t update_bytes;          /* contribution-block pool in HBM, bytes per matrix */
+    int64_t batch;                 /* matrices factorised together (same pattern) */
+    int64_t fail_col;              /* first failing pivot column (permuted index), -1 if none */
+    double  flops_factor;          /* floating-point operations of the numeric phase */
+    double  t_order_s, t_symbolic_s; /* host seconds spent in ordering / symbolic analysis */
+} cs3_info;
+
+const char *cs3_last_error(void);
+int cs3_version(void);
+int cs3_device_count(void);        /* 0 when no GPU is visible */
+
+/* ---- ordering and symbolic kernels (host side of the library) ----------
+ * Flat-array functions in the style of csc_numba.py; integer outputs are
+ * bit-exact with the oracle.  They need no GPU. */
+
+/* cs_amd lineage.  order 0: natural, 1: amd(A+A').  q[n] out. */
+int cs3_amd(int64_t order, int64_t m, int64_t n, const int32_t *Ap,
+            const int32_t *Ai, int32_t *q);
+/* cs_etree lineage: (Ap, Ai) is the upper triangle of a symmetric pattern. */
+int cs3_etree(int64_t n, const int32_t *Ap, const int32_t *Ai, int32_t *parent);
+/* cs_post lineage. */
+int cs3_post(int64_t n, const int32_t *parent, int32_t *post);
+/* cs_counts lineage: column counts of the Cholesky factor of that pattern. */
+int cs3_counts(int64_t n, const int32_t *Ap, const int32_t *Ai,
+               const int32_t *parent, const int32_t *post, int32_t *colcount);
+
+/* ---- analysis: ordering + symbolic + supernodes + schedule --------------
+ * cs_sqr / cs_schol lineage.  Pattern only; values come with cs3_factor*.
+ * kind: cs3_kind.  order: cs3_order; with CS3_ORDER_GIVEN q_given[n] is the
+ * fill-reducing order to use.  For CS3_CHOLESKY (Ap, Ai) may hold the full
+ * symmetric pattern or only one triangle.  Rows inside a column need not be
+ * sorted (csc_numba.py:334-335); nnz is Ap[n], not the array length
+ * (csc.py:138,480).  batch >= 1 matrices share this pattern. */
+int cs3_analyze(int64_t kind, int64_t order, int64_t n, const int32_t *Ap,
+                const int32_t *Ai, const int32_t *q_given, int64_t batch,
+                cs3_handle *out);
+int cs3_free(cs3_handle h);
+int cs3_get_info(cs3_handle h, cs3_info *info);
+/* Ordering results.  Any pointer may be NULL.
+ * q_amd[n]:   the fill-reducing order before postordering (what cs_amd returns)
+ * parent[n], post[n], colcount[n]: etree / postorder / column counts of
+ *             A(q_amd,q_amd) + its transpose, as cs_schol computes them
+ * q[n]:       the pivot order actually used = q_amd[post[.]]
+ * pinv[n]:    row permutation of the factorisation, pinv[q[k]] = k */
+int cs3_get_ordering(cs3_handle h, int32_t *q_amd, int32_t *parent, int32_t *post,
+                     int32_t *colcount, int32_t *q, int32_t *pinv);
+/* Supernode partition: sn_ptr[nsuper+1] first pivot column of each supernode,
+ * sn_parent[nsuper], sn_level[nsuper]. */
+int cs3_get_supernodes(cs3_handle h, int32_t *sn_ptr, int32_t *sn_parent, int32_t *sn_level);
+
+/* ---- numeric factorisation (cs_lu / cs_chol lineage) --------------------
+ * P A Q = L U with P = Q' (static diagonal pivots in AMD order), L unit lower,
+ * U upper; or P A P' = L L'.  Ax[batch][nnz_a] in the entry order of the
+ * analysed (Ap, Ai).  tol as in cs_lu: a diagonal pivot is accepted when
+ * |pivot| >= tol * max|column below|; rejected pivots give CS3_ERR_PIVOT
+ * (there is no CPU fallback).  tol <= 0 disables the test. */
+int cs3_factor(cs3_handle h, const double *Ax, double tol);
+int cs3_factor_dev(cs3_handle h, const double *Ax_dev, double tol, void *stream);
+/* Deferred status of the last cs3_factor_dev (synchronises the stream). */
+int cs3_factor_status(cs3_handle h, void *stream);
+
+/* ---- solves (cs_lsolve / cs_usolve / cs_ltsolve / cs_lusol / cs_cholsol) -
+ * X is [n, k] row-major (the reference's multi-vector layout, csc.py:409-414),
+ * overwritten in place.  With batch > 1, X is [batch, n, k].
+ * cs3_solve:   full solve A x = b including both permutations
+ * cs3_lsolve:  x = L \ x     in the permuted (pivot-order) space
+ * cs3_usolve:  x = U \ x     (for Cholesky: x = L' \ x) */
+int cs3_solve(cs3_handle h, double *X, int64_t k);
+int cs3_solve_dev(cs3_handle h, double *X_dev, int64_t k, void *stream);
+int cs3_lsolve_dev(cs3_handle h, double *X_dev, int64_t k, void *stream);
+int cs3_usolve_dev(cs3_handle h, double *X_dev, int64_t k, void *stream);
+
+/* ---- factors back to the host in CSparse's CSC form ---------------------
+ * L: diagonal FIRST in each column (unit for LU); U: diagonal LAST; row
+ * indices sorted otherwise.  Sizes from cs3_info.nnz_l / nnz_u.  NumPy-style
+ * ownership: the caller allocates, the library fills.  b = matrix index in
+ * the batch.  For Cholesky Up/Ui/Ux must be NULL. */
+int cs3_get_factors(cs3_handle h, int64_t b, int32_t *Lp, int32_t *Li, double *Lx,
+                    int32_t *Up, int32_t *Ui, double *Ux);
+
+/* ---- general triangular solves on caller-supplied CSC factors -----------
+ * cs_lsolve / cs_usolve lineage, the csc_lsolve_f(n, Lp, Li, Lx, x) shape of
+ * x[n, k] row-major, in place; diagonal first (L) /
+ * last (U) in each column.  Level-scheduled on the device. */
+int cs3_csc_lsolve(int64_t n, const int32_t *Lp, const int32_t *Li, const double *Lx,
+                   double *x, int64_t k);
+int cs3_csc_usolve(int64_t n, const int32_t *Up, const int32_t *Ui, const double *Ux,
+                   double *x, int64_t k);
+
+/* ---- neighbours of the path -----------------------
+ * y = A x on the device, csc_mat_vec_ff (csc_numba.py:309-328) semantics;
+ * X [n, k] and Y [m, k] row-major as csc_matvecs (sparsetools/csc.h:68-84). */
+int cs3_csc_matvec(int64_t m, int64_t n, const int32_t *Ap, const int32_t *Ai,
+                   const double *Ax, const double *X, double *Y, int64_t k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -40,7 +40,6 @@ struct cs3_handle_s {
     hipGraphExec_t factor_graph = nullptr;
     double factor_graph_inv_tol = 0.0;
     std::map<int, hipGraphExec_t> solve_graphs;   // keyed by nrhs
-    double *d_ax = nullptr;                       // staging for the host-pointer entry points
     i64 *d_lmap = nullptr, *d_umap = nullptr;
     double *d_lx = nullptr, *d_ux = nullptr;
     long long fail_col = -1;
@@ -75,32 +74,44 @@ int ensure_device(cs3_handle h)
     const Symbolic &S = h->S;
     DeviceFactor &D = h->D;
     D.kind = S.kind; D.n = S.n; D.nnz_a = S.nnzA; D.batch = h->batch;
-    D.vals_size = S.vals_size; D.cb_size = S.cb_size; D.cv_size = S.cv_size;
-
+    D.vals_size = S.vals_size; D.pool_size = S.pool_size; D.cv_size = S.cv_size; D.big_begin = S.big_begin;
     std::vector<FrontMeta> meta(S.nsuper);
     for (i32 s = 0; s < S.nsuper; ++s) {
         FrontMeta &m = meta[s];
-        m.lpan = S.lpan_off[s]; m.upan = S.upan_off[s]; m.cb = S.cb_off[s]; m.cv = S.cv_off[s];
+        m.lpan = S.lpan_off[s]; m.upan = S.upan_off[s]; m.cv = S.cv_off[s];
         m.rel = S.rel_ptr[s]; m.st = S.st_ptr[s];
         m.c0 = S.sn_ptr[s];
         m.r = (int) (S.st_ptr[s + 1] - S.st_ptr[s]);
         m.w = S.sn_ptr[s + 1] - S.sn_ptr[s];
+        m.u_sk = S.u_sk[s]; m.u_sj = S.u_sj[s];
         m.child_begin = S.child_ptr[s]; m.child_end = S.child_ptr[s + 1];
         m.parent = S.sn_parent[s];
     }
-    std::vector<int> vsrc(S.vals_size, -1);
-    for (i64 p = 0; p < S.nnzA; ++p)
-        if (S.amap[p] >= 0) vsrc[S.amap[p]] = (int) p;
+    std::vector<FrontDesc> fdesc(S.nsuper);
+    for (i32 t = 0; t < S.nsuper; ++t) {
+        const i32 s = S.sched[t];
+        FrontDesc &f = fdesc[t];
+        f.lpan = S.lpan_off[s]; f.upan = S.upan_off[s]; f.cb = S.cb_off[s];
+        f.asm_begin = S.asm_ptr[s]; f.asm_count = (int) (S.asm_ptr[s + 1] - S.asm_ptr[s]);
+        f.c0 = S.sn_ptr[s];
+        f.r = (int) (S.st_ptr[s + 1] - S.st_ptr[s]);
+        f.w = S.sn_ptr[s + 1] - S.sn_ptr[s];
+        f.cb_ld = S.cb_ld[s]; f.u_sk = S.u_sk[s]; f.u_sj = S.u_sj[s];
+        f.parent = S.sn_parent[s];
+    }
     int rc;
     if ((rc = upload(&D.meta, meta))) return rc;
+    if ((rc = upload(&D.fdesc, fdesc))) return rc;
     if ((rc = upload(&D.sched, S.sched))) return rc;
     if ((rc = upload(&D.child_idx, S.child_idx))) return rc;
     if ((rc = upload(&D.rel_idx, S.rel_idx))) return rc;
     if ((rc = upload(&D.st_idx, S.st_idx))) return rc;
-    if ((rc = upload(&D.vsrc, vsrc))) return rc;
+    if ((rc = upload(&D.asm_src, S.asm_src))) return rc;
+    if ((rc = upload(&D.asm_tgt, S.asm_tgt))) return rc;
+    if ((rc = upload(&D.long_src, S.long_src))) return rc;
     if ((rc = upload(&D.q, S.q))) return rc;
-    CS3_HIP(hipMalloc((void **) &D.vals, std::max<size_t>(1, (size_t) (D.batch * D.vals_size)) * sizeof(double)));
-    CS3_HIP(hipMalloc((void **) &D.cb, std::max<size_t>(1, (size_t) (D.batch * D.cb_size)) * sizeof(double)));
+    CS3_HIP(hipMalloc((void **) &D.pool, std::max<size_t>(1, (size_t) (D.batch * D.pool_size)) * sizeof(double)));
+    CS3_HIP(hipMalloc((void **) &D.ax, std::max<size_t>(1, (size_t) (D.batch * D.nnz_a)) * sizeof(double)));
     CS3_HIP(hipMalloc((void **) &D.status, sizeof(int)));
     CS3_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
     const char *ng = std::getenv("CS3_NO_GRAPH");
@@ -145,7 +156,8 @@ int run_factor(cs3_handle h, const double *ax_dev, double tol, hipStream_t st)
     DeviceFactor &D = h->D;
     const double inv_tol = (tol > 0.0) ? 1.0 / tol : HUGE_VAL;
     CS3_HIP(hipMemsetAsync(D.status, 0x7f, sizeof(int), st));   // 0x7f7f7f7f = clean
-    CS3_HIP(launch_assemble(D, ax_dev, st));
+    if (ax_dev != D.ax && D.nnz_a > 0)
+        CS3_HIP(hipMemcpyAsync(D.ax, ax_dev, (size_t) (D.batch * D.nnz_a) * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (h->use_graph) {
         if (h->factor_graph && h->factor_graph_inv_tol != inv_tol) {
             (void) hipGraphExecDestroy(h->factor_graph);
@@ -308,8 +320,8 @@ int cs3_free(cs3_handle h)
         if (h->factor_graph) (void) hipGraphExecDestroy(h->factor_graph);
         drop_solve_graphs(h);
         if (h->cap_stream) (void) hipStreamDestroy(h->cap_stream);
-        void *ptrs[] = {D.meta, D.sched, D.child_idx, D.rel_idx, D.st_idx, D.vsrc, D.q, D.vals, D.cb, D.cv,
-                        D.xp, D.status, h->d_ax, h->d_lmap, h->d_umap, h->d_lx, h->d_ux};
+        void *ptrs[] = {D.meta, D.fdesc, D.sched, D.child_idx, D.rel_idx, D.st_idx, D.asm_src, D.asm_tgt, D.long_src,
+                        D.q, D.ax, D.pool, D.cv, D.xp, D.status, h->d_lmap, h->d_umap, h->d_lx, h->d_ux};
         for (void *p : ptrs) if (p) (void) hipFree(p);
     }
     delete h;
@@ -381,9 +393,8 @@ int cs3_factor(cs3_handle h, const double *Ax, double tol)
     if (!Ax && h->S.nnzA > 0) { set_error("cs3_factor: null values"); return CS3_ERR_ARG; }
     if ((rc = ensure_device(h))) return rc;
     const size_t count = (size_t) (h->batch * h->S.nnzA);
-    if (!h->d_ax) CS3_HIP(hipMalloc((void **) &h->d_ax, std::max<size_t>(1, count) * sizeof(double)));
-    if (count) CS3_HIP(hipMemcpy(h->d_ax, Ax, count * sizeof(double), hipMemcpyHostToDevice));
-    if ((rc = run_factor(h, h->d_ax, tol, nullptr))) return rc;
+    if (count) CS3_HIP(hipMemcpy(h->D.ax, Ax, count * sizeof(double), hipMemcpyHostToDevice));
+    if ((rc = run_factor(h, h->D.ax, tol, nullptr))) return rc;
     return read_status(h, nullptr);
 }
 
@@ -439,7 +450,7 @@ int cs3_get_factors(cs3_handle h, int64_t b, int32_t *Lp, int32_t *Li, double *L
     if (Ui) std::memcpy(Ui, S.Ui.data(), (size_t) unz * sizeof(int32_t));
     if (!Lx && !Ux) return CS3_OK;
     if (!h->factored) { set_error("cs3_get_factors: values requested before a successful factorisation"); return CS3_ERR_STATE; }
-    const double *vals = h->D.vals + b * h->D.vals_size;
+    const double *vals = h->D.pool + b * h->D.pool_size;
     if (Lx) {
         if (!h->d_lmap) { if ((rc = upload(&h->d_lmap, S.Lmap))) return rc; }
         if (!h->d_lx) CS3_HIP(hipMalloc((void **) &h->d_lx, std::max<size_t>(1, (size_t) lnz) * sizeof(double)));

@@ -8,34 +8,48 @@
 
 namespace cs3 {
 
-// One front (supernode).  Offsets are element offsets into the per-matrix
-// vals / cb / cv pools and into the rel_idx / st_idx index arrays.
+// One front (supernode), indexed by supernode id: what the solve kernels read.
+// Offsets are element offsets into the per-matrix pool / cv pool and into the
+// rel_idx / st_idx index arrays.
 struct FrontMeta {
-    long long lpan, upan, cb, cv, rel, st;
+    long long lpan, upan, cv, rel, st;
     int c0, r, w;
+    int u_sk, u_sj;               // U(k, j) = pool[upan + k*u_sk + (j-w)*u_sj]
     int child_begin, child_end;   // range in child_idx
     int parent;                   // -1 for a root
+};
+
+// The same front as the factorisation kernels see it, stored in SCHEDULE order
+// so that block b of a launch group reads entry first + b with no indirection.
+struct FrontDesc {
+    long long lpan, upan, cb;     // pool offsets: L panel (ld r), U panel, contribution block
+    long long asm_begin;          // first entry of the assembly list
+    int asm_count;                // entries in it (multiple of 64)
+    int c0, r, w;
+    int cb_ld, u_sk, u_sj;
+    int parent;
 };
 
 // Everything the kernels read, resident in HBM for the life of the handle.
 struct DeviceFactor {
     int kind = CS3_LU;
     long long n = 0, nnz_a = 0, batch = 1;
-    long long vals_size = 0, cb_size = 0, cv_size = 0;
+    long long vals_size = 0, pool_size = 0, cv_size = 0;
+    long long big_begin = 0;      // big-front buffers: pool[big_begin, vals_size), zeroed per factorisation
     FrontMeta *meta = nullptr;
+    FrontDesc *fdesc = nullptr;
     int *sched = nullptr, *child_idx = nullptr, *rel_idx = nullptr, *st_idx = nullptr;
-    int *vsrc = nullptr;          // [vals_size] entry of A feeding each panel slot, or -1
+    int *asm_src = nullptr, *asm_tgt = nullptr, *long_src = nullptr;
     int *q = nullptr;             // [n] pivot order
-    double *vals = nullptr;       // [batch][vals_size]
-    double *cb = nullptr;         // [batch][cb_size]
+    double *ax = nullptr;         // [batch][nnz_a] values of A (stable address for the graph)
+    double *pool = nullptr;       // [batch][pool_size]  factors | contribution blocks
     double *cv = nullptr;         // [batch][cv_size * nrhs_cap]
     double *xp = nullptr;         // [batch][n * nrhs_cap] right-hand sides in pivot order
     long long nrhs_cap = 0;
-    int *status = nullptr;        // [1] first failing pivot column, INT_MAX when clean
+    int *status = nullptr;        // [1] first failing pivot column, 0x7f7f7f7f when clean
 };
 
 hipError_t prepare_kernels();
-hipError_t launch_assemble(const DeviceFactor &D, const double *Ax_dev, hipStream_t st);
 hipError_t launch_factor_levels(const DeviceFactor &D, const std::vector<LaunchGroup> &groups,
                                 double inv_tol, hipStream_t st);
 hipError_t launch_solve_levels(const DeviceFactor &D, const std::vector<LaunchGroup> &groups,

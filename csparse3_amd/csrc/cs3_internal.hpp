@@ -37,6 +37,8 @@ struct LaunchGroup {          // fronts of one level that share a kernel configu
     int cls;                  // FrontClass
     i32 first, count;         // range in Symbolic::sched
     i32 max_r;                // largest front order in the group (sizes dynamic LDS)
+    i32 max_w;                // widest supernode in the group (block steps of the big path)
+    i64 max_asm;              // longest assembly list in the group
 };
 
 struct Symbolic {
@@ -49,28 +51,44 @@ struct Symbolic {
     std::vector<i32> parent, colcount;
     // supernodes
     i32 nsuper = 0;
-    std::vector<i32> sn_ptr, col2sn, sn_parent, sn_level;
+    std::vector<i32> sn_ptr, col2sn, sn_parent, sn_level, sn_class;
     std::vector<i64> st_ptr;                  // [nsuper+1] into st_idx
     std::vector<i32> st_idx;                  // sorted row structure; first w entries = own columns
     std::vector<i32> child_ptr, child_idx;    // children of each supernode, ascending
-    std::vector<i64> lpan_off, upan_off, cb_off;   // per supernode, offsets in vals / cb pool / cv pool
+    // One pool per matrix: [ persistent factors | contribution blocks ].
+    //   fronts that fit the LDS: L panel r x w (ld r), U panel (r-w) x w, in the factor part;
+    //                            contribution block (r-w)^2 compact in the second part
+    //   big fronts: one dense r x r buffer (ld r) in the factor part; its L panel, U panel
+    //               and contribution block are sub-blocks of that buffer
+    std::vector<i64> lpan_off, upan_off, cb_off;   // pool offsets
+    std::vector<i32> cb_ld;                   // leading dimension of the contribution block
+    std::vector<i32> u_sk, u_sj;              // U(k, j) = pool[upan + k*u_sk + (j-w)*u_sj]
     std::vector<i64> cv_off;                  // contribution-vector offsets (forward solve)
     std::vector<i64> rel_ptr;                 // [nsuper+1] into rel_idx (length r - w each)
     std::vector<i32> rel_idx;                 // position of my update rows in the parent's structure
-    i64 vals_size = 0, cb_size = 0, cv_size = 0;
+    i64 vals_size = 0, cb_size = 0, cv_size = 0, pool_size = 0;
+    i64 big_begin = 0;                        // big-front buffers occupy [big_begin, vals_size)
+    // assembly: every front entry = sum of its sources (A entries, children's
+    // contribution blocks), listed sorted by target.  src >= 0: pool offset;
+    // src < 0: entry ~src of Ax.  Runs (equal targets) never straddle a
+    // 64-entry boundary; padding entries carry target ASM_DUMMY.
+    std::vector<i64> asm_ptr;                 // [nsuper+1]
+    std::vector<i32> asm_src, asm_tgt;
+    std::vector<i32> long_src;                // sources of runs longer than 64
     // schedule
     i32 nlevels = 0;
     std::vector<i32> sched;                   // supernode ids grouped by (level, class)
     std::vector<LaunchGroup> groups;          // ascending level
-    // assembly of A into the panels: vals[amap[p]] += Ax[p]
-    std::vector<i64> amap;
     // factors in CSC form
     std::vector<i32> Lp, Li, Up, Ui;
-    std::vector<i64> Lmap, Umap;              // offsets in vals; -1 = constant 1.0 (unit diagonal)
+    std::vector<i64> Lmap, Umap;              // pool offsets; -1 = constant 1.0 (unit diagonal)
     i64 max_front = 0, max_width = 0;
     double flops = 0.0;
     double t_order = 0.0, t_symbolic = 0.0;
 };
+
+constexpr i32 ASM_DUMMY = 0x3fffffff;         // padding target: contributes nowhere
+constexpr i32 ASM_LONG = 0x40000000;          // flag on a target: sources are long_src[src .. src+count)
 
 // Full analysis.  order: cs3_order.  Throws std::runtime_error on bad input.
 void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,

@@ -265,18 +265,18 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         }
     }
 
-    // ---- 7. storage offsets; child -> parent relative indices
+    // ---- 7. size classes, pool layout, child -> parent relative indices
+    S.sn_class.assign(ns, 0);
     S.lpan_off.assign(ns, 0); S.upan_off.assign(ns, 0); S.cb_off.assign(ns, 0); S.cv_off.assign(ns, 0);
+    S.cb_ld.assign(ns, 0); S.u_sk.assign(ns, 0); S.u_sj.assign(ns, 0);
     S.rel_ptr.assign(ns + 1, 0);
-    i64 voff = 0, cboff = 0, cvoff = 0;
+    auto width = [&](i32 s) -> i64 { return S.sn_ptr[s + 1] - S.sn_ptr[s]; };
+    auto order_r = [&](i32 s) -> i64 { return S.st_ptr[s + 1] - S.st_ptr[s]; };
+    i64 voff = 0, cvoff = 0;
     S.max_front = 0; S.max_width = 0; S.flops = 0.0;
-    for (i32 s = 0; s < ns; ++s) {
-        const i64 w = S.sn_ptr[s + 1] - S.sn_ptr[s];
-        const i64 r = S.st_ptr[s + 1] - S.st_ptr[s];
-        const i64 nb = r - w;
-        S.lpan_off[s] = voff; voff += r * w;
-        if (kind == CS3_LU) { S.upan_off[s] = voff; voff += nb * w; }
-        S.cb_off[s] = cboff; cboff += nb * nb;
+    for (i32 s = 0; s < ns; ++s) {                   // panels of the LDS-resident fronts
+        const i64 w = width(s), r = order_r(s), nb = r - w;
+        S.sn_class[s] = front_class(r);
         S.cv_off[s] = cvoff; cvoff += nb;
         S.rel_ptr[s + 1] = S.rel_ptr[s] + nb;
         S.max_front = std::max(S.max_front, r);
@@ -285,17 +285,38 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
             double m = (double) (r - k - 1);
             S.flops += (kind == CS3_LU) ? (m + 2.0 * m * m) : (m + m * (m + 1.0) + 1.0);
         }
+        if (S.sn_class[s] == FC_BIG) continue;
+        S.lpan_off[s] = voff; voff += r * w;
+        if (kind == CS3_LU) { S.upan_off[s] = voff; voff += nb * w; S.u_sk[s] = (i32) nb; S.u_sj[s] = 1; }
     }
-    S.vals_size = voff; S.cb_size = cboff; S.cv_size = cvoff;
+    S.big_begin = voff;
+    for (i32 s = 0; s < ns; ++s) {                   // dense buffers of the big fronts
+        if (S.sn_class[s] != FC_BIG) continue;
+        const i64 w = width(s), r = order_r(s);
+        S.lpan_off[s] = voff;
+        S.upan_off[s] = voff + w * r; S.u_sk[s] = 1; S.u_sj[s] = (i32) r;
+        S.cb_off[s] = voff + w + w * r; S.cb_ld[s] = (i32) r;
+        voff += r * r;
+    }
+    S.vals_size = voff;
+    i64 cboff = voff;
+    for (i32 s = 0; s < ns; ++s) {                   // compact contribution blocks
+        if (S.sn_class[s] == FC_BIG) continue;
+        const i64 nb = order_r(s) - width(s);
+        S.cb_off[s] = cboff; S.cb_ld[s] = (i32) nb;
+        cboff += nb * nb;
+    }
+    S.cb_size = cboff - voff; S.cv_size = cvoff; S.pool_size = cboff;
+    if (S.pool_size >= ((i64) 1 << 30)) throw std::runtime_error("analyze: factor pool exceeds 32-bit offsets");
     S.rel_idx.resize(S.rel_ptr[ns]);
     for (i32 s = 0; s < ns; ++s) {
         i32 p = S.sn_parent[s];
         if (p < 0) continue;
-        const i32 w = S.sn_ptr[s + 1] - S.sn_ptr[s];
+        const i32 w = (i32) width(s);
         const i32 *mine = S.st_idx.data() + S.st_ptr[s] + w;
-        const i64 nb = S.st_ptr[s + 1] - S.st_ptr[s] - w;
+        const i64 nb = order_r(s) - w;
         const i32 *theirs = S.st_idx.data() + S.st_ptr[p];
-        const i64 rp = S.st_ptr[p + 1] - S.st_ptr[p];
+        const i64 rp = order_r(p);
         i32 *rel = S.rel_idx.data() + S.rel_ptr[s];
         i64 t = 0;
         for (i64 i = 0; i < nb; ++i) {
@@ -306,7 +327,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         }
     }
 
-    // ---- 8. levels (leaves = 0) and launch groups by (level, size class)
+    // ---- 8. levels (leaves = 0)
     S.sn_level.assign(ns, 0);
     for (i32 s = 0; s < ns; ++s) {          // children precede parents in postorder
         i32 p = S.sn_parent[s];
@@ -314,34 +335,24 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     }
     S.nlevels = 0;
     for (i32 s = 0; s < ns; ++s) S.nlevels = std::max(S.nlevels, S.sn_level[s] + 1);
-    S.sched.resize(ns);
-    std::iota(S.sched.begin(), S.sched.end(), 0);
-    auto cls_of = [&](i32 s) { return front_class(S.st_ptr[s + 1] - S.st_ptr[s]); };
-    std::stable_sort(S.sched.begin(), S.sched.end(), [&](i32 a, i32 b) {
-        if (S.sn_level[a] != S.sn_level[b]) return S.sn_level[a] < S.sn_level[b];
-        return cls_of(a) < cls_of(b);
-    });
-    S.groups.clear();
-    for (i32 t = 0; t < ns; ) {
-        i32 s = S.sched[t];
-        LaunchGroup g{S.sn_level[s], cls_of(s), t, 0, 0};
-        while (t < ns && S.sn_level[S.sched[t]] == g.level && cls_of(S.sched[t]) == g.cls) {
-            g.max_r = std::max<i32>(g.max_r, (i32) (S.st_ptr[S.sched[t] + 1] - S.st_ptr[S.sched[t]]));
-            ++t;
-        }
-        g.count = t - g.first;
-        S.groups.push_back(g);
-    }
 
-    // ---- 9. where each entry of A lands in the panels
+    // ---- 9. assembly lists: every entry of a front is the sum of its sources
     auto find_row = [&](i32 s, i32 row) -> i64 {
         const i32 *st = S.st_idx.data() + S.st_ptr[s];
-        const i64 r = S.st_ptr[s + 1] - S.st_ptr[s];
+        const i64 r = order_r(s);
         const i32 *it = std::lower_bound(st, st + r, row);
         if (it == st + r || *it != row) throw std::runtime_error("analyze: entry outside the symbolic structure");
         return it - st;
     };
-    S.amap.assign(nnzA, -1);
+    // target index of front entry (ti, tj): LDS image index for resident fronts
+    // (leading dimension r | 1), absolute pool offset inside the r x r buffer for big ones
+    auto target_of = [&](i32 s, i64 ti, i64 tj) -> i32 {
+        const i64 r = order_r(s);
+        if (S.sn_class[s] == FC_BIG) return (i32) (S.lpan_off[s] + ti + tj * r);
+        return (i32) (ti + tj * (r | 1));
+    };
+    struct Item { i32 tgt, src; };
+    std::vector<std::vector<Item>> from_a(ns);
     bool has_upper = false;
     if (kind == CS3_CHOLESKY)
         for (i64 j = 0; j < n && !has_upper; ++j)
@@ -356,27 +367,84 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
                 if (!use) continue;
                 if (i2 < j2) std::swap(i2, j2);
             }
-            if (i2 >= j2) {
-                i32 s = S.col2sn[j2];
-                i64 c0 = S.sn_ptr[s], r = S.st_ptr[s + 1] - S.st_ptr[s];
-                S.amap[p] = S.lpan_off[s] + find_row(s, i2) + (j2 - c0) * r;
-            } else {
-                i32 s = S.col2sn[i2];
-                i64 c0 = S.sn_ptr[s], c1 = S.sn_ptr[s + 1], w = c1 - c0;
-                i64 r = S.st_ptr[s + 1] - S.st_ptr[s];
-                if (j2 < c1) S.amap[p] = S.lpan_off[s] + (i2 - c0) + (j2 - c0) * r;
-                else S.amap[p] = S.upan_off[s] + (find_row(s, j2) - w) + (i2 - c0) * (r - w);
-            }
+            const i32 s = S.col2sn[std::min(i2, j2)];
+            const i64 c0 = S.sn_ptr[s], c1 = S.sn_ptr[s + 1];
+            const i64 ti = (i2 < c1) ? i2 - c0 : find_row(s, i2);
+            const i64 tj = (j2 < c1) ? j2 - c0 : find_row(s, j2);
+            from_a[s].push_back(Item{target_of(s, ti, tj), (i32) ~p});
         }
     }
+    S.asm_ptr.assign(ns + 1, 0);
+    S.asm_src.clear(); S.asm_tgt.clear(); S.long_src.clear();
+    {
+        std::vector<Item> items;
+        for (i32 s = 0; s < ns; ++s) {
+            items.assign(from_a[s].begin(), from_a[s].end());
+            std::vector<Item>().swap(from_a[s]);
+            for (i32 cp = S.child_ptr[s]; cp < S.child_ptr[s + 1]; ++cp) {
+                const i32 c = S.child_idx[cp];
+                const i64 nbc = order_r(c) - width(c);
+                const i32 *rel = S.rel_idx.data() + S.rel_ptr[c];
+                const i64 base = S.cb_off[c], ldc = S.cb_ld[c];
+                for (i64 jj = 0; jj < nbc; ++jj)
+                    for (i64 ii = (kind == CS3_CHOLESKY ? jj : 0); ii < nbc; ++ii)
+                        items.push_back(Item{target_of(s, rel[ii], rel[jj]), (i32) (base + ii + jj * ldc)});
+            }
+            std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.tgt < b.tgt; });
+            const i64 start = (i64) S.asm_tgt.size();
+            auto pad_to_boundary = [&]() {
+                while (((i64) S.asm_tgt.size() - start) % 64 != 0) { S.asm_tgt.push_back(ASM_DUMMY); S.asm_src.push_back(0); }
+            };
+            for (size_t a0 = 0; a0 < items.size(); ) {
+                size_t a1 = a0;
+                while (a1 < items.size() && items[a1].tgt == items[a0].tgt) ++a1;
+                const i64 len = (i64) (a1 - a0);
+                const i64 pos = ((i64) S.asm_tgt.size() - start) % 64;
+                if (len > 64) {            // rare: one lane sums the run serially
+                    if (pos + 2 > 64) pad_to_boundary();
+                    S.asm_tgt.push_back(items[a0].tgt | ASM_LONG); S.asm_src.push_back((i32) S.long_src.size());
+                    S.asm_tgt.push_back(ASM_DUMMY); S.asm_src.push_back((i32) len);
+                    for (size_t t = a0; t < a1; ++t) S.long_src.push_back(items[t].src);
+                } else {
+                    if (pos + len > 64) pad_to_boundary();
+                    for (size_t t = a0; t < a1; ++t) { S.asm_tgt.push_back(items[t].tgt); S.asm_src.push_back(items[t].src); }
+                }
+                a0 = a1;
+            }
+            pad_to_boundary();
+            S.asm_ptr[s + 1] = (i64) S.asm_tgt.size();
+        }
+    }
+    if (S.asm_tgt.size() >= ((size_t) 1 << 31)) throw std::runtime_error("analyze: assembly list exceeds 32-bit offsets");
 
-    // ---- 10. factors in CSC form: L diagonal first, U diagonal last
+    // ---- 10. launch groups by (level, size class)
+    S.sched.resize(ns);
+    std::iota(S.sched.begin(), S.sched.end(), 0);
+    std::stable_sort(S.sched.begin(), S.sched.end(), [&](i32 a, i32 b) {
+        if (S.sn_level[a] != S.sn_level[b]) return S.sn_level[a] < S.sn_level[b];
+        return S.sn_class[a] < S.sn_class[b];
+    });
+    S.groups.clear();
+    for (i32 t = 0; t < ns; ) {
+        i32 s = S.sched[t];
+        LaunchGroup g{S.sn_level[s], S.sn_class[s], t, 0, 0, 0, 0};
+        while (t < ns && S.sn_level[S.sched[t]] == g.level && S.sn_class[S.sched[t]] == g.cls) {
+            const i32 f = S.sched[t];
+            g.max_r = std::max<i32>(g.max_r, (i32) order_r(f));
+            g.max_w = std::max<i32>(g.max_w, (i32) width(f));
+            g.max_asm = std::max<i64>(g.max_asm, S.asm_ptr[f + 1] - S.asm_ptr[f]);
+            ++t;
+        }
+        g.count = t - g.first;
+        S.groups.push_back(g);
+    }
+
+    // ---- 11. factors in CSC form: L diagonal first, U diagonal last
     S.Lp.assign(n + 1, 0);
     for (i64 j = 0; j < n; ++j) S.Lp[j + 1] = S.Lp[j] + S.colcount[j];
     S.Li.resize(S.Lp[n]); S.Lmap.resize(S.Lp[n]);
     for (i32 s = 0; s < ns; ++s) {
-        const i64 c0 = S.sn_ptr[s], w = S.sn_ptr[s + 1] - c0;
-        const i64 r = S.st_ptr[s + 1] - S.st_ptr[s];
+        const i64 c0 = S.sn_ptr[s], w = width(s), r = order_r(s);
         const i32 *st = S.st_idx.data() + S.st_ptr[s];
         for (i64 jj = 0; jj < w; ++jj) {
             i64 p = S.Lp[c0 + jj];
@@ -389,8 +457,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     if (kind == CS3_LU) {
         S.Up.assign(n + 1, 0);
         for (i32 s = 0; s < ns; ++s) {
-            const i64 c0 = S.sn_ptr[s], w = S.sn_ptr[s + 1] - c0;
-            const i64 r = S.st_ptr[s + 1] - S.st_ptr[s];
+            const i64 w = width(s), r = order_r(s);
             const i32 *st = S.st_idx.data() + S.st_ptr[s];
             for (i64 kk = 0; kk < w; ++kk)
                 for (i64 i = kk; i < r; ++i) ++S.Up[st[i] + 1];
@@ -399,15 +466,14 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         S.Ui.resize(S.Up[n]); S.Umap.resize(S.Up[n]);
         std::vector<i32> fill(S.Up.begin(), S.Up.end() - 1);
         for (i32 s = 0; s < ns; ++s) {          // pivot rows ascending => rows sorted, diagonal last
-            const i64 c0 = S.sn_ptr[s], w = S.sn_ptr[s + 1] - c0;
-            const i64 r = S.st_ptr[s + 1] - S.st_ptr[s], nb = r - w;
+            const i64 c0 = S.sn_ptr[s], w = width(s), r = order_r(s);
             const i32 *st = S.st_idx.data() + S.st_ptr[s];
             for (i64 kk = 0; kk < w; ++kk) {
                 for (i64 i = kk; i < r; ++i) {
                     i32 p = fill[st[i]]++;
                     S.Ui[p] = (i32) (c0 + kk);
                     S.Umap[p] = (i < w) ? S.lpan_off[s] + kk + i * r
-                                        : S.upan_off[s] + (i - w) + kk * nb;
+                                        : S.upan_off[s] + kk * S.u_sk[s] + (i - w) * S.u_sj[s];
                 }
             }
         }

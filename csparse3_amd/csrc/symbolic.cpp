@@ -8,6 +8,7 @@
 // rows inside a column in any order.
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <numeric>
 #include <stdexcept>
 
@@ -185,30 +186,150 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     cholesky_counts(n, Bp.data(), Bi.data(), S.parent_amd.data(), S.post_amd.data(),
                     S.count_amd.data());
 
-    // ---- 4. pivot order = fill-reducing order composed with the postorder
+    // ---- 4. pivot order = fill-reducing order composed with a postorder of the
+    //         etree.  Any postorder gives the same factors up to a symmetric
+    //         permutation; this one visits the TALLEST child of every node last, so
+    //         that the child on the critical path sits directly in front of its
+    //         parent and can be merged with it (step 5b).  S.post_amd keeps the
+    //         plain ascending-children postorder (what cs_post returns).
     S.q.resize(n); S.pinv.resize(n); S.parent.resize(n); S.colcount.resize(n);
+    std::vector<i32> post2(n);
+    {
+        std::vector<i32> height(n, 0), first(n, -1), sib(n, -1), tallest(n, -1);
+        for (i64 j = 0; j < n; ++j) {                  // parent[j] > j in the fill-reducing labels
+            i32 p = S.parent_amd[j];
+            if (p >= 0) height[p] = std::max(height[p], height[j] + 1);
+        }
+        for (i64 j = 0; j < n; ++j) {
+            i32 p = S.parent_amd[j];
+            if (p < 0) continue;
+            if (tallest[p] < 0 || height[j] >= height[tallest[p]]) tallest[p] = (i32) j;
+        }
+        for (i64 j = n - 1; j >= 0; --j) {             // tallest child first in the list built backwards
+            i32 p = S.parent_amd[j];
+            if (p < 0 || tallest[p] != j) continue;
+            sib[j] = first[p]; first[p] = (i32) j;
+        }
+        for (i64 j = n - 1; j >= 0; --j) {             // the others in front of it, ascending
+            i32 p = S.parent_amd[j];
+            if (p < 0 || tallest[p] == j) continue;
+            sib[j] = first[p]; first[p] = (i32) j;
+        }
+        std::vector<i32> stack;
+        i64 k = 0;
+        for (i64 root = 0; root < n; ++root) {
+            if (S.parent_amd[root] >= 0) continue;
+            stack.assign(1, (i32) root);
+            while (!stack.empty()) {
+                i32 v = stack.back();
+                i32 c = first[v];
+                if (c == -1) { stack.pop_back(); post2[k++] = v; }
+                else { first[v] = sib[c]; stack.push_back(c); }
+            }
+        }
+    }
     std::vector<i32> newlab(n);
-    for (i64 k = 0; k < n; ++k) newlab[S.post_amd[k]] = (i32) k;
+    for (i64 k = 0; k < n; ++k) newlab[post2[k]] = (i32) k;
     for (i64 k = 0; k < n; ++k) {
-        i32 old = S.post_amd[k];
+        i32 old = post2[k];
         S.q[k] = S.q_amd[old];
         S.pinv[S.q[k]] = (i32) k;
         S.parent[k] = S.parent_amd[old] < 0 ? -1 : newlab[S.parent_amd[old]];
         S.colcount[k] = S.count_amd[old];
     }
 
-    // ---- 5. supernodes: maximal runs j-1 -> j with parent[j-1] = j and
-    //         colcount[j] = colcount[j-1] - 1 (identical structure below the run)
-    S.col2sn.resize(n);
-    S.sn_ptr.clear();
+    // ---- 5a. fundamental supernodes: maximal runs j-1 -> j with parent[j-1] = j
+    //          and colcount[j] = colcount[j-1] - 1 (identical structure below the run)
+    std::vector<i32> fsn_ptr, fcol2sn(n);
     for (i64 j = 0; j < n; ++j) {
         bool join = j > 0 && S.parent[j - 1] == j && S.colcount[j] == S.colcount[j - 1] - 1;
-        if (!join) S.sn_ptr.push_back((i32) j);
-        S.col2sn[j] = (i32) S.sn_ptr.size() - 1;
+        if (!join) fsn_ptr.push_back((i32) j);
+        fcol2sn[j] = (i32) fsn_ptr.size() - 1;
+    }
+    const i32 nf = (i32) fsn_ptr.size();
+    fsn_ptr.push_back((i32) n);
+    std::vector<i32> fparent(nf, -1);
+    for (i32 s = 0; s < nf; ++s) {
+        i32 last = fsn_ptr[s + 1] - 1;
+        if (S.parent[last] >= 0) fparent[s] = fcol2sn[S.parent[last]];
+    }
+    // exact row structure of every fundamental supernode (size = column count)
+    std::vector<i64> fst_ptr(nf + 1, 0);
+    for (i32 s = 0; s < nf; ++s) fst_ptr[s + 1] = fst_ptr[s] + S.colcount[fsn_ptr[s]];
+    std::vector<i32> fst_idx(fst_ptr[nf]);
+    {
+        std::vector<i32> fchild_ptr(nf + 1, 0), fchild_idx;
+        for (i32 s = 0; s < nf; ++s) if (fparent[s] >= 0) ++fchild_ptr[fparent[s] + 1];
+        for (i32 s = 0; s < nf; ++s) fchild_ptr[s + 1] += fchild_ptr[s];
+        fchild_idx.resize(fchild_ptr[nf]);
+        std::vector<i32> fill(fchild_ptr.begin(), fchild_ptr.end() - 1);
+        for (i32 s = 0; s < nf; ++s) if (fparent[s] >= 0) fchild_idx[fill[fparent[s]]++] = s;
+        std::vector<i32> mark(n, -1);
+        for (i32 s = 0; s < nf; ++s) {
+            const i32 c0 = fsn_ptr[s], c1 = fsn_ptr[s + 1], w = c1 - c0;
+            i32 *st = fst_idx.data() + fst_ptr[s];
+            const i64 r = fst_ptr[s + 1] - fst_ptr[s];
+            i64 cnt = 0;
+            auto add = [&](i32 i2) {
+                if (i2 >= c1 && mark[i2] != s) {
+                    mark[i2] = s;
+                    if (cnt >= r) throw std::runtime_error("analyze: structure exceeds column count");
+                    st[cnt++] = i2;
+                }
+            };
+            for (i32 j = c0; j < c1; ++j) st[cnt++] = j;
+            for (i32 j = c0; j < c1; ++j) {
+                i64 col = S.q[j];
+                for (i64 p = Cp[col]; p < Cp[col + 1]; ++p) add(S.pinv[Ci[p]]);
+            }
+            for (i32 cp = fchild_ptr[s]; cp < fchild_ptr[s + 1]; ++cp) {
+                i32 c = fchild_idx[cp];
+                i32 wc = fsn_ptr[c + 1] - fsn_ptr[c];
+                for (i64 p = fst_ptr[c] + wc; p < fst_ptr[c + 1]; ++p) add(fst_idx[p]);
+            }
+            if (cnt != r) throw std::runtime_error("analyze: structure does not match column count");
+            std::sort(st + w, st + r);
+        }
+    }
+
+    // ---- 5b. relaxed amalgamation: a supernode absorbs its LAST child (the one
+    //          whose columns end where its own begin) when that adds few explicit
+    //          zeros.  Every dependent launch costs microseconds on the device,
+    //          so a shallower tree is worth far more than the padded flops.
+    double relax_z = 0.5; i64 relax_w = 8;
+    if (const char *e = std::getenv("CS3_RELAX_Z")) relax_z = std::atof(e);
+    if (const char *e = std::getenv("CS3_RELAX_W")) relax_w = std::atoll(e);
+    std::vector<i64> mw(nf), mr(nf), mc0(nf);
+    std::vector<double> mz(nf, 0.0);
+    std::vector<char> alive(nf, 1);
+    for (i32 s = 0; s < nf; ++s) {
+        mw[s] = fsn_ptr[s + 1] - fsn_ptr[s]; mr[s] = fst_ptr[s + 1] - fst_ptr[s]; mc0[s] = fsn_ptr[s];
+    }
+    const i64 lds_r = 136;
+    for (i32 s = 0; s < nf; ++s) {
+        const i32 p = fparent[s];
+        if (p < 0 || fsn_ptr[s + 1] != mc0[p]) continue;       // not the last child of (merged) p
+        const i64 wn = mw[s] + mw[p], rn = mw[s] + mr[p], nbs = mr[s] - mw[s];
+        const double zn = mz[s] + mz[p] + (double) mw[s] * (double) (mr[p] - nbs);
+        const double tn = (double) wn * (double) rn - 0.5 * (double) wn * (double) (wn - 1);
+        bool ok = (wn <= relax_w) || (zn <= relax_z * tn);
+        if (rn > lds_r && std::max(mr[s], mr[p]) <= lds_r) ok = false;   // do not push a resident front out of the LDS
+        if (!ok) continue;
+        mw[p] = wn; mr[p] = rn; mz[p] = zn; mc0[p] = mc0[s]; alive[s] = 0;
+    }
+    S.col2sn.resize(n);
+    S.sn_ptr.clear();
+    std::vector<i32> top_of;                 // fundamental supernode that closes each merged one
+    for (i32 s = 0; s < nf; ++s) {
+        if (!alive[s]) continue;
+        S.sn_ptr.push_back((i32) mc0[s]);
+        top_of.push_back(s);
     }
     S.nsuper = (i32) S.sn_ptr.size();
     S.sn_ptr.push_back((i32) n);
     const i32 ns = S.nsuper;
+    for (i32 s = 0; s < ns; ++s)
+        for (i32 j = S.sn_ptr[s]; j < S.sn_ptr[s + 1]; ++j) S.col2sn[j] = s;
     S.sn_parent.assign(ns, -1);
     for (i32 s = 0; s < ns; ++s) {
         i32 last = S.sn_ptr[s + 1] - 1;
@@ -224,45 +345,23 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
             if (S.sn_parent[s] >= 0) S.child_idx[fill[S.sn_parent[s]]++] = s;
     }
 
-    // ---- 6. row structure of every front: own columns, then the sorted union of
-    //         A's entries below the supernode and the children's update rows
+    // ---- 6. row structure of every (merged) front: its own columns, then the
+    //         structure below the supernode that closes it (a superset of every
+    //         absorbed member's, so the extra rows hold explicit zeros)
     S.st_ptr.assign(ns + 1, 0);
-    for (i32 s = 0; s < ns; ++s) S.st_ptr[s + 1] = S.st_ptr[s] + S.colcount[S.sn_ptr[s]];
+    for (i32 s = 0; s < ns; ++s) {
+        const i32 t = top_of[s];
+        const i64 wt = fsn_ptr[t + 1] - fsn_ptr[t];
+        S.st_ptr[s + 1] = S.st_ptr[s] + (S.sn_ptr[s + 1] - S.sn_ptr[s]) + (fst_ptr[t + 1] - fst_ptr[t] - wt);
+    }
     S.st_idx.resize(S.st_ptr[ns]);
-    {
-        std::vector<i32> mark(n, -1);
-        for (i32 s = 0; s < ns; ++s) {
-            const i32 c0 = S.sn_ptr[s], c1 = S.sn_ptr[s + 1], w = c1 - c0;
-            i32 *st = S.st_idx.data() + S.st_ptr[s];
-            const i64 r = S.st_ptr[s + 1] - S.st_ptr[s];
-            i64 cnt = 0;
-            for (i32 j = c0; j < c1; ++j) st[cnt++] = j;
-            for (i32 j = c0; j < c1; ++j) {
-                i64 col = S.q[j];
-                for (i64 p = Cp[col]; p < Cp[col + 1]; ++p) {
-                    i32 i2 = S.pinv[Ci[p]];
-                    if (i2 >= c1 && mark[i2] != s) {
-                        mark[i2] = s;
-                        if (cnt >= r) throw std::runtime_error("analyze: structure exceeds column count");
-                        st[cnt++] = i2;
-                    }
-                }
-            }
-            for (i32 cp = S.child_ptr[s]; cp < S.child_ptr[s + 1]; ++cp) {
-                i32 c = S.child_idx[cp];
-                i32 wc = S.sn_ptr[c + 1] - S.sn_ptr[c];
-                for (i64 p = S.st_ptr[c] + wc; p < S.st_ptr[c + 1]; ++p) {
-                    i32 i2 = S.st_idx[p];
-                    if (i2 >= c1 && mark[i2] != s) {
-                        mark[i2] = s;
-                        if (cnt >= r) throw std::runtime_error("analyze: structure exceeds column count");
-                        st[cnt++] = i2;
-                    }
-                }
-            }
-            if (cnt != r) throw std::runtime_error("analyze: structure does not match column count");
-            std::sort(st + w, st + r);
-        }
+    for (i32 s = 0; s < ns; ++s) {
+        const i32 t = top_of[s];
+        const i64 wt = fsn_ptr[t + 1] - fsn_ptr[t];
+        i32 *st = S.st_idx.data() + S.st_ptr[s];
+        i64 cnt = 0;
+        for (i32 j = S.sn_ptr[s]; j < S.sn_ptr[s + 1]; ++j) st[cnt++] = j;
+        for (i64 p = fst_ptr[t] + wt; p < fst_ptr[t + 1]; ++p) st[cnt++] = fst_idx[p];
     }
 
     // ---- 7. size classes, pool layout, child -> parent relative indices
@@ -439,41 +538,45 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         S.groups.push_back(g);
     }
 
-    // ---- 11. factors in CSC form: L diagonal first, U diagonal last
+    // ---- 11. factors in CSC form: L diagonal first, U diagonal last.  Only the
+    //          exact structure is exported; the explicit zeros that amalgamation
+    //          added stay inside the panels.
     S.Lp.assign(n + 1, 0);
     for (i64 j = 0; j < n; ++j) S.Lp[j + 1] = S.Lp[j] + S.colcount[j];
     S.Li.resize(S.Lp[n]); S.Lmap.resize(S.Lp[n]);
-    for (i32 s = 0; s < ns; ++s) {
-        const i64 c0 = S.sn_ptr[s], w = width(s), r = order_r(s);
-        const i32 *st = S.st_idx.data() + S.st_ptr[s];
-        for (i64 jj = 0; jj < w; ++jj) {
-            i64 p = S.Lp[c0 + jj];
-            for (i64 i = jj; i < r; ++i, ++p) {
-                S.Li[p] = st[i];
-                S.Lmap[p] = (i == jj && kind == CS3_LU) ? -1 : S.lpan_off[s] + i + jj * r;
-            }
-        }
-    }
     if (kind == CS3_LU) {
         S.Up.assign(n + 1, 0);
-        for (i32 s = 0; s < ns; ++s) {
-            const i64 w = width(s), r = order_r(s);
-            const i32 *st = S.st_idx.data() + S.st_ptr[s];
+        for (i32 f = 0; f < nf; ++f) {
+            const i64 w = fsn_ptr[f + 1] - fsn_ptr[f], r = fst_ptr[f + 1] - fst_ptr[f];
+            const i32 *st = fst_idx.data() + fst_ptr[f];
             for (i64 kk = 0; kk < w; ++kk)
                 for (i64 i = kk; i < r; ++i) ++S.Up[st[i] + 1];
         }
         for (i64 j = 0; j < n; ++j) S.Up[j + 1] += S.Up[j];
         S.Ui.resize(S.Up[n]); S.Umap.resize(S.Up[n]);
-        std::vector<i32> fill(S.Up.begin(), S.Up.end() - 1);
-        for (i32 s = 0; s < ns; ++s) {          // pivot rows ascending => rows sorted, diagonal last
+    }
+    {
+        std::vector<i32> ufill;
+        if (kind == CS3_LU) ufill.assign(S.Up.begin(), S.Up.end() - 1);
+        for (i32 f = 0; f < nf; ++f) {          // pivot rows ascending => U rows sorted, diagonal last
+            const i64 fc0 = fsn_ptr[f], fw = fsn_ptr[f + 1] - fc0, fr = fst_ptr[f + 1] - fst_ptr[f];
+            const i32 *fst = fst_idx.data() + fst_ptr[f];
+            const i32 s = S.col2sn[fc0];
             const i64 c0 = S.sn_ptr[s], w = width(s), r = order_r(s);
-            const i32 *st = S.st_idx.data() + S.st_ptr[s];
-            for (i64 kk = 0; kk < w; ++kk) {
-                for (i64 i = kk; i < r; ++i) {
-                    i32 p = fill[st[i]]++;
-                    S.Ui[p] = (i32) (c0 + kk);
-                    S.Umap[p] = (i < w) ? S.lpan_off[s] + kk + i * r
-                                        : S.upan_off[s] + kk * S.u_sk[s] + (i - w) * S.u_sj[s];
+            for (i64 kk = 0; kk < fw; ++kk) {
+                const i64 jj = fc0 + kk - c0;                 // column / pivot row inside the merged front
+                i64 lp = S.Lp[fc0 + kk];
+                for (i64 i = kk; i < fr; ++i, ++lp) {
+                    const i64 row = fst[i];
+                    const i64 ti = (row < c0 + w) ? row - c0 : find_row(s, (i32) row);
+                    S.Li[lp] = (i32) row;
+                    S.Lmap[lp] = (i == kk && kind == CS3_LU) ? -1 : S.lpan_off[s] + ti + jj * r;
+                    if (kind == CS3_LU) {
+                        const i32 up = ufill[row]++;
+                        S.Ui[up] = (i32) (fc0 + kk);
+                        S.Umap[up] = (ti < w) ? S.lpan_off[s] + jj + ti * r
+                                              : S.upan_off[s] + jj * S.u_sk[s] + (ti - w) * S.u_sj[s];
+                    }
                 }
             }
         }

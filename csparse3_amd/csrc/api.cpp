@@ -88,6 +88,7 @@ int ensure_device(cs3_handle h)
         m.parent = S.sn_parent[s];
     }
     std::vector<FrontDesc> fdesc(S.nsuper);
+    i64 dbuf_size = 0;
     for (i32 t = 0; t < S.nsuper; ++t) {
         const i32 s = S.sched[t];
         FrontDesc &f = fdesc[t];
@@ -98,7 +99,10 @@ int ensure_device(cs3_handle h)
         f.w = S.sn_ptr[s + 1] - S.sn_ptr[s];
         f.cb_ld = S.cb_ld[s]; f.u_sk = S.u_sk[s]; f.u_sj = S.u_sj[s];
         f.parent = S.sn_parent[s];
+        f.dbuf = 0;
+        if (S.sn_class[s] == FC_BIG) { f.dbuf = dbuf_size; dbuf_size += (i64) ((f.w + 31) / 32) * 1024; }
     }
+    D.dbuf_size = dbuf_size;
     int rc;
     if ((rc = upload(&D.meta, meta))) return rc;
     if ((rc = upload(&D.fdesc, fdesc))) return rc;
@@ -111,6 +115,7 @@ int ensure_device(cs3_handle h)
     if ((rc = upload(&D.long_src, S.long_src))) return rc;
     if ((rc = upload(&D.q, S.q))) return rc;
     CS3_HIP(hipMalloc((void **) &D.pool, std::max<size_t>(1, (size_t) (D.batch * D.pool_size)) * sizeof(double)));
+    CS3_HIP(hipMalloc((void **) &D.dbuf, std::max<size_t>(1, (size_t) (D.batch * D.dbuf_size)) * sizeof(double)));
     CS3_HIP(hipMalloc((void **) &D.ax, std::max<size_t>(1, (size_t) (D.batch * D.nnz_a)) * sizeof(double)));
     CS3_HIP(hipMalloc((void **) &D.status, sizeof(int)));
     CS3_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
@@ -321,7 +326,7 @@ int cs3_free(cs3_handle h)
         drop_solve_graphs(h);
         if (h->cap_stream) (void) hipStreamDestroy(h->cap_stream);
         void *ptrs[] = {D.meta, D.fdesc, D.sched, D.child_idx, D.rel_idx, D.st_idx, D.asm_src, D.asm_tgt, D.long_src,
-                        D.q, D.ax, D.pool, D.cv, D.xp, D.status, h->d_lmap, h->d_umap, h->d_lx, h->d_ux};
+                        D.q, D.ax, D.pool, D.dbuf, D.cv, D.xp, D.status, h->d_lmap, h->d_umap, h->d_lx, h->d_ux};
         for (void *p : ptrs) if (p) (void) hipFree(p);
     }
     delete h;

@@ -24,6 +24,7 @@ struct FrontMeta {
 struct FrontDesc {
     long long lpan, upan, cb;     // pool offsets: L panel (ld r), U panel, contribution block
     long long asm_begin;          // first entry of the assembly list
+    long long dbuf;               // big fronts: parked diagonal blocks, BIG_NB^2 doubles per block step
     int asm_count;                // entries in it (multiple of 64)
     int c0, r, w;
     int cb_ld, u_sk, u_sj;
@@ -43,6 +44,8 @@ struct DeviceFactor {
     int *q = nullptr;             // [n] pivot order
     double *ax = nullptr;         // [batch][nnz_a] values of A (stable address for the graph)
     double *pool = nullptr;       // [batch][pool_size]  factors | contribution blocks
+    double *dbuf = nullptr;       // [batch][dbuf_size] diagonal blocks of the big fronts in flight
+    long long dbuf_size = 0;
     double *cv = nullptr;         // [batch][cv_size * nrhs_cap]
     double *xp = nullptr;         // [batch][n * nrhs_cap] right-hand sides in pivot order
     long long nrhs_cap = 0;

@@ -31,6 +31,14 @@ namespace cs3 {
 // (pool offset, or ~index into Ax) and the wave sums each run with a fixed
 // shuffle tree: every front entry is written exactly once, by one lane, and
 // the summation order never changes from run to run.
+// Load-then-select: a predicated `cond ? p[i] : 0` makes hipcc branch around the
+// load and wait for it alone; loading from a safe address keeps loads in flight.
+__device__ __forceinline__ double load_if(const double *__restrict__ p, long long off, bool ok)
+{
+    const double v = p[ok ? off : 0];
+    return ok ? v : 0.0;
+}
+
 constexpr int ASM_DUMMY_T = 0x3fffffff;
 constexpr int ASM_LONG_T = 0x40000000;
 constexpr int GATHER_UNROLL = 4;
@@ -38,16 +46,19 @@ constexpr int GATHER_UNROLL = 4;
 __device__ __forceinline__ double gather_value(int t, int s, int s_next, const double *__restrict__ pool,
                                                const double *__restrict__ ax, const int *__restrict__ long_src)
 {
-    if (t == ASM_DUMMY_T) return 0.0;
-    if (t & ASM_LONG_T) {                       // rare: more than 64 sources for one entry
-        double acc = 0.0;
+    const bool is_long = (t & ASM_LONG_T) != 0 && t != ASM_DUMMY_T;
+    const bool plain = !is_long && t != ASM_DUMMY_T;
+    const int sp = plain ? s : 0;
+    const double *src = (sp >= 0) ? pool + sp : ax + ~sp;      // one unconditional load per entry
+    double v = *src;
+    if (!plain) v = 0.0;
+    if (is_long) {                              // rare: more than 64 sources for one entry
         for (int k = 0; k < s_next; ++k) {
             const int q = long_src[s + k];
-            acc += (q >= 0) ? pool[q] : ax[~q];
+            v += (q >= 0) ? pool[q] : ax[~q];
         }
-        return acc;
     }
-    return (s >= 0) ? pool[s] : ax[~s];
+    return v;
 }
 
 // On return v holds the run total in the last lane of each run.
@@ -83,9 +94,10 @@ __device__ __forceinline__ void gather_front(long long asm_begin, int nchunks, i
 #pragma unroll
         for (int u = 0; u < GATHER_UNROLL; ++u) {
             const bool valid = c0 + u < nchunks;
-            const long long idx = asm_begin + (long long) (c0 + u) * 64 + lane;
-            t[u] = valid ? asm_tgt[idx] : ASM_DUMMY_T;
-            s[u] = valid ? asm_src[idx] : 0;
+            const long long idx = asm_begin + (long long) (valid ? c0 + u : c0) * 64 + lane;
+            const int tl = asm_tgt[idx], sl = asm_src[idx];
+            t[u] = valid ? tl : ASM_DUMMY_T;
+            s[u] = valid ? sl : 0;
         }
 #pragma unroll
         for (int u = 0; u < GATHER_UNROLL; ++u) {
@@ -206,26 +218,158 @@ k_big_gather(const FrontDesc *__restrict__ fdesc, int first,
                       [&](int t, double v) { pool[t] = v; });
 }
 
-// Panel step kb: every workgroup factors the diagonal block D = F[kb:ke, kb:ke]
-// on its own in LDS (cheap, and it avoids a grid-wide hand-off), then each
-// thread solves one row of L21 (x U_D = f) or one column of U12 (L_D u = f).
+// Blocked right-looking LU / Cholesky with ONE launch per block step.
+// Launch kb does, tile by tile over the trailing matrix F[kb:, kb:]:
+//   * every tile applies the update of the PREVIOUS panel  C -= L[:, kp:kb] U[kp:kb, :]
+//     (K = BIG_NB, operands written by the previous launch);
+//   * tiles on the new block column / block row also need the new diagonal block
+//     D = F[kb:ke, kb:ke] (updated the same way); each of them recomputes and factors
+//     it in LDS on its own (cheap, and it avoids any hand-off inside the launch), then
+//     solves its tile:  L[I, kb:ke] = C U_D^-1   or   U[kb:ke, J] = L_D^-1 C.
+// The factored D cannot be written into F during the launch (the other tiles read the
+// unfactored block), so tile (0,0) parks it in dbuf; the closing launch (kb >= w:
+// last update only) copies the parked blocks into place.
+// Tile index 0 = the panel block [kb, ke); index t >= 1 = 64 rows/columns from ke + 64 (t-1).
 template <int KIND>
-__global__ void __launch_bounds__(64)
-k_big_panel(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__restrict__ pool_all,
-            long long pool_stride, double inv_tol, int *status)
+__global__ void __launch_bounds__(256)
+k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__restrict__ pool_all,
+           long long pool_stride, double *__restrict__ dbuf_all, long long dbuf_stride,
+           double inv_tol, int *status, int batch)
 {
+    __shared__ double As[BIG_NB][64 + 1];       // As[k][i] = L(row0 + i, kp + k)
+    __shared__ double Bs[BIG_NB][64 + 1];       // Bs[k][j] = U(kp + k, col0 + j)
+    __shared__ double Ad[BIG_NB][BIG_NB + 1];   // Ad[k][i] = L(kb + i, kp + k)
+    __shared__ double Bd[BIG_NB][BIG_NB + 1];   // Bd[k][j] = U(kp + k, kb + j)
     __shared__ double D[BIG_NB][BIG_NB + 1];
-    const FrontDesc d = fdesc[first + blockIdx.z];
+    __shared__ double T[64][BIG_NB + 1];
+    const FrontDesc d = fdesc[first + blockIdx.z / batch];     // grid (tiles, tiles, fronts * batch)
+    const int bz = blockIdx.z % batch;
     const int r = d.r, w = d.w;
-    if (kb >= w) return;
-    const int ke = min(kb + BIG_NB, w), bw = ke - kb;
-    double *F = pool_all + (long long) blockIdx.y * pool_stride + d.lpan;
+    const int nblk = (w + BIG_NB - 1) / BIG_NB;
+    if (kb > nblk * BIG_NB) return;
+    const bool has_panel = kb < w;
+    const int ke = has_panel ? min(kb + BIG_NB, w) : w, bw = ke - kb;
+    const int kp = kb - BIG_NB, pw = min(kb, w) - kp;          // previous panel [kp, kp + pw), if kb > 0
+    double *F = pool_all + (long long) bz * pool_stride + d.lpan;
+    double *dbuf = dbuf_all + (long long) bz * dbuf_stride + d.dbuf;
     const long long ld = r;
     const int tid = threadIdx.x;
+    const int bi = blockIdx.x, bj = blockIdx.y;
+    const int nsl = (r - ke + 63) / 64;
+    if (bi > nsl || bj > nsl) return;
+    if (KIND == CS3_CHOLESKY && bi < bj) return;
+    if (!has_panel) {
+        if (bi == 0 && bj == 0) {                   // closing launch: parked diagonal blocks go home
+            for (int blk = 0; blk < nblk; ++blk) {
+                const int k0 = blk * BIG_NB, cw = min(BIG_NB, w - k0);
+                for (int e = tid; e < cw * cw; e += 256) {
+                    const int i = e % cw, j = e / cw;
+                    if (KIND == CS3_LU || i >= j) F[(k0 + i) + (k0 + j) * ld] = dbuf[blk * (BIG_NB * BIG_NB) + i + j * BIG_NB];
+                }
+            }
+        }
+        if (bi == 0 || bj == 0) return;
+    }
+    const int row0 = (bi == 0) ? kb : ke + (bi - 1) * 64, nrow = (bi == 0) ? bw : min(64, r - row0);
+    const int col0 = (bj == 0) ? kb : ke + (bj - 1) * 64, ncol = (bj == 0) ? bw : min(64, r - col0);
+    const bool needs_d = has_panel && (bi == 0 || bj == 0);
+    const int tx = tid % 16, ty = tid / 16;
 
-    for (int e = tid; e < bw * bw; e += 64) {
-        const int i = e % bw, j = e / bw;
-        D[i][j] = F[(kb + i) + (kb + j) * ld];
+    // ---- stage the previous panel's operands (and D's) in LDS
+    if (kb > 0) {
+        for (int e = tid; e < BIG_NB * 64; e += 256) {
+            const int i = e % 64, k = e / 64;
+            As[k][i] = load_if(F, (row0 + i) + (long long) (kp + k) * ld, k < pw && i < nrow);
+        }
+        if (KIND == CS3_LU) {
+            for (int e = tid; e < BIG_NB * 64; e += 256) {
+                const int k = e % BIG_NB, j = e / BIG_NB;
+                Bs[k][j] = load_if(F, (kp + k) + (long long) (col0 + j) * ld, k < pw && j < ncol);
+            }
+        } else {
+            for (int e = tid; e < BIG_NB * 64; e += 256) {
+                const int j = e % 64, k = e / 64;
+                Bs[k][j] = load_if(F, (col0 + j) + (long long) (kp + k) * ld, k < pw && j < ncol);
+            }
+        }
+        if (needs_d) {
+            for (int e = tid; e < BIG_NB * BIG_NB; e += 256) {
+                const int i = e % BIG_NB, k = e / BIG_NB;
+                Ad[k][i] = load_if(F, (kb + i) + (long long) (kp + k) * ld, k < pw && i < bw);
+            }
+            if (KIND == CS3_LU) {
+                for (int e = tid; e < BIG_NB * BIG_NB; e += 256) {
+                    const int k = e % BIG_NB, j = e / BIG_NB;
+                    Bd[k][j] = load_if(F, (kp + k) + (long long) (kb + j) * ld, k < pw && j < bw);
+                }
+            } else {
+                for (int e = tid; e < BIG_NB * BIG_NB; e += 256) {
+                    const int j = e % BIG_NB, k = e / BIG_NB;
+                    Bd[k][j] = load_if(F, (kb + j) + (long long) (kp + k) * ld, k < pw && j < bw);
+                }
+            }
+        }
+    }
+    // my 4 x 4 outputs and D's 4 entries, loaded while the staging loads are in flight
+    double acc[4][4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tx + 16 * u, j = ty + 16 * v;
+            acc[u][v] = load_if(F, (row0 + i) + (long long) (col0 + j) * ld, i < nrow && j < ncol);
+        }
+    const int di = tid & 31, dj = tid >> 5;                    // D entries (di, dj + 8c)
+    double dacc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        dacc[c] = load_if(F, (kb + di) + (long long) (kb + dj + 8 * c) * ld, needs_d && di < bw && dj + 8 * c < bw);
+    __syncthreads();
+    if (kb > 0) {
+#pragma unroll 8
+        for (int k = 0; k < BIG_NB; ++k) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = As[k][tx + 16 * u]; b[u] = Bs[k][ty + 16 * u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] -= a[u] * b[v];
+        }
+        if (needs_d) {
+#pragma unroll 8
+            for (int k = 0; k < BIG_NB; ++k) {
+                const double a = Ad[k][di];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) dacc[c] -= a * Bd[k][dj + 8 * c];
+            }
+        }
+    }
+    if (!needs_d) {                                 // plain trailing tile: store and leave
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = tx + 16 * u, j = ty + 16 * v;
+                if (i < nrow && j < ncol && (KIND == CS3_LU || row0 + i >= col0 + j))
+                    F[(row0 + i) + (long long) (col0 + j) * ld] = acc[u][v];
+            }
+        return;
+    }
+
+    // ---- factor D in LDS
+#pragma unroll
+    for (int c = 0; c < 4; ++c) D[di][dj + 8 * c] = dacc[c];
+    if (bi > 0) {                                   // block-column tile: T[row][col]
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) T[tx + 16 * u][ty + 16 * v] = acc[u][v];
+    } else if (bj > 0) {                            // block-row tile: T[col][row]
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) T[ty + 16 * v][tx + 16 * u] = acc[u][v];
     }
     __syncthreads();
     for (int k = 0; k < bw; ++k) {
@@ -233,24 +377,27 @@ k_big_panel(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__re
         if (KIND == CS3_LU) {
             if (tid > k && tid < bw) D[tid][k] /= piv;
             __syncthreads();
-            for (int e = tid; e < (bw - k - 1) * (bw - k - 1); e += 64) {
-                const int i = k + 1 + e % (bw - k - 1), j = k + 1 + e / (bw - k - 1);
-                D[i][j] -= D[i][k] * D[k][j];
+            const int i = k + 1 + di;
+            if (i < bw) {
+                const double l = D[i][k];
+                for (int j = k + 1 + dj; j < bw; j += 8) D[i][j] -= l * D[k][j];
             }
         } else {
             const double dg = sqrt(piv);
             if (tid > k && tid < bw) D[tid][k] /= dg;
             __syncthreads();
             if (tid == 0) D[k][k] = (piv > 0.0) ? dg : -1.0;
-            for (int e = tid; e < (bw - k - 1) * (bw - k - 1); e += 64) {
-                const int i = k + 1 + e % (bw - k - 1), j = k + 1 + e / (bw - k - 1);
-                if (i >= j) D[i][j] -= D[i][k] * D[j][k];
+            const int i = k + 1 + di;
+            if (i < bw) {
+                const double l = D[i][k];
+                for (int j = k + 1 + dj; j < bw; j += 8) if (i >= j) D[i][j] -= l * D[j][k];
             }
         }
         __syncthreads();
     }
-    if (blockIdx.x == 0) {
-        for (int e = tid; e < bw * bw; e += 64) {
+    if (bi == 0 && bj == 0) {                       // park the factored block, check its pivots
+        double *db = dbuf + (long long) (kb / BIG_NB) * (BIG_NB * BIG_NB);
+        for (int e = tid; e < bw * bw; e += 256) {
             const int i = e % bw, j = e / bw;
             const double v = D[i][j];
             if (KIND == CS3_LU) {
@@ -259,106 +406,42 @@ k_big_panel(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__re
             } else if (i == j) {
                 if (!(v > 0.0)) flag_column(status, d.c0 + kb + j);
             }
-            if (KIND == CS3_LU || i >= j) F[(kb + i) + (kb + j) * ld] = v;
+            db[i + j * BIG_NB] = v;
         }
+        return;
     }
-    const int below = r - ke;
-    const int g = blockIdx.x * 64 + tid;
-    if (g < below) {                              // one row of L21:  x U_D = f  (Cholesky: x L_D' = f)
-        const int i = ke + g;
-        double x[BIG_NB];
+    if (bi > 0) {
+        if (tid < 64 && tid < nrow) {              // x U_D = t  (Cholesky: x L_D' = t), one row per lane
+            double x[BIG_NB];
 #pragma unroll
-        for (int c = 0; c < BIG_NB; ++c) x[c] = (c < bw) ? F[i + (kb + c) * ld] : 0.0;
+            for (int c = 0; c < BIG_NB; ++c) {
+                if (c < bw) {
+                    double v = T[tid][c];
 #pragma unroll
-        for (int c = 0; c < BIG_NB; ++c) {
-            if (c < bw) {
-                double acc = x[c];
-#pragma unroll
-                for (int k = 0; k < BIG_NB; ++k)
-                    if (k < c) acc -= x[k] * ((KIND == CS3_LU) ? D[k][c] : D[c][k]);
-                x[c] = acc / D[c][c];
-                if (KIND == CS3_LU && !(fabs(x[c]) <= inv_tol)) flag_column(status, d.c0 + kb + c);
+                    for (int k = 0; k < c; ++k) v -= x[k] * ((KIND == CS3_LU) ? D[k][c] : D[c][k]);
+                    x[c] = v / D[c][c];
+                    if (KIND == CS3_LU && !(fabs(x[c]) <= inv_tol)) flag_column(status, d.c0 + kb + c);
+                    F[(row0 + tid) + (long long) (kb + c) * ld] = x[c];
+                } else {
+                    x[c] = 0.0;
+                }
             }
-        }
-#pragma unroll
-        for (int c = 0; c < BIG_NB; ++c) if (c < bw) F[i + (kb + c) * ld] = x[c];
-    } else if (KIND == CS3_LU && g < 2 * below) {  // one column of U12:  L_D u = f, L_D unit lower
-        const int j = ke + (g - below);
-        double u[BIG_NB];
-#pragma unroll
-        for (int c = 0; c < BIG_NB; ++c) u[c] = (c < bw) ? F[(kb + c) + j * ld] : 0.0;
-#pragma unroll
-        for (int c = 0; c < BIG_NB; ++c) {
-            if (c < bw) {
-                double acc = u[c];
-#pragma unroll
-                for (int k = 0; k < BIG_NB; ++k)
-                    if (k < c) acc -= D[c][k] * u[k];
-                u[c] = acc;
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < BIG_NB; ++c) if (c < bw) F[(kb + c) + j * ld] = u[c];
-    }
-}
-
-// Trailing update after panel kb:  F[ke:, ke:] -= L[ke:, kb:ke] * U[kb:ke, ke:]
-// 64 x 64 tile per workgroup of 256 threads, 4 x 4 outputs per thread.
-template <int KIND>
-__global__ void __launch_bounds__(256)
-k_big_update(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__restrict__ pool_all,
-             long long pool_stride, int batch)
-{
-    __shared__ double As[BIG_NB][64 + 1];      // As[k][i] = L[ke + ti0 + i, kb + k]
-    __shared__ double Bs[BIG_NB][64 + 1];      // Bs[k][j] = U[kb + k, ke + tj0 + j]
-    const FrontDesc d = fdesc[first + blockIdx.z / batch];     // grid (tiles, tiles, fronts * batch)
-    const int r = d.r, w = d.w;
-    if (kb >= w) return;
-    const int ke = min(kb + BIG_NB, w), bw = ke - kb;
-    const int tiles = (r - ke + 63) / 64;
-    const int bi = blockIdx.x, bj = blockIdx.y;
-    if (bi >= tiles || bj >= tiles) return;
-    if (KIND == CS3_CHOLESKY && bi < bj) return;
-    double *F = pool_all + (long long) (blockIdx.z % batch) * pool_stride + d.lpan;
-    const long long ld = r;
-    const int ti0 = ke + bi * 64, tj0 = ke + bj * 64;
-    const int tid = threadIdx.x;
-    for (int e = tid; e < BIG_NB * 64; e += 256) {
-        const int i = e % 64, k = e / 64;
-        As[k][i] = (k < bw && ti0 + i < r) ? F[(ti0 + i) + (kb + k) * ld] : 0.0;
-    }
-    if (KIND == CS3_LU) {
-        for (int e = tid; e < BIG_NB * 64; e += 256) {
-            const int k = e % BIG_NB, j = e / BIG_NB;
-            Bs[k][j] = (k < bw && tj0 + j < r) ? F[(kb + k) + (tj0 + j) * ld] : 0.0;
         }
     } else {
-        for (int e = tid; e < BIG_NB * 64; e += 256) {
-            const int j = e % 64, k = e / 64;
-            Bs[k][j] = (k < bw && tj0 + j < r) ? F[(tj0 + j) + (kb + k) * ld] : 0.0;
-        }
-    }
-    __syncthreads();
-    const int tx = tid % 16, ty = tid / 16;
-    double acc[4][4] = {};
-#pragma unroll 8
-    for (int k = 0; k < BIG_NB; ++k) {
-        double a[4], b[4];
+        if (tid < 64 && tid < ncol) {              // L_D u = t, L_D unit lower, one column per lane
+            double u[BIG_NB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { a[u] = As[k][tx + 16 * u]; b[u] = Bs[k][ty + 16 * u]; }
+            for (int c = 0; c < BIG_NB; ++c) {
+                if (c < bw) {
+                    double v = T[tid][c];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * b[v];
-    }
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const int j = tj0 + ty + 16 * v;
-        if (j >= r) continue;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = ti0 + tx + 16 * u;
-            if (i < r && (KIND == CS3_LU || i >= j)) F[i + j * ld] -= acc[u][v];
+                    for (int k = 0; k < c; ++k) v -= D[c][k] * u[k];
+                    u[c] = v;
+                    F[(kb + c) + (long long) (col0 + tid) * ld] = v;
+                } else {
+                    u[c] = 0.0;
+                }
+            }
         }
     }
 }
@@ -386,7 +469,7 @@ k_solve_fwd(const FrontMeta *__restrict__ meta, const int *__restrict__ sched, i
     const double *L = vals + m.lpan;
 
     for (int i = i0; i < r; i += IS)
-        v[i * KT + t] = (i < w && live) ? X[(long long) (m.c0 + i) * nrhs + tt] : 0.0;
+        v[i * KT + t] = load_if(X, (long long) (m.c0 + i) * nrhs + tt, i < w && live);
     __syncthreads();
     for (int cp = m.child_begin; cp < m.child_end; ++cp) {
         const FrontMeta mc = meta[child_idx[cp]];
@@ -436,7 +519,7 @@ k_solve_bwd(const FrontMeta *__restrict__ meta, const int *__restrict__ sched, i
 
     for (int i = i0; i < r; i += IS) {
         const long long row = (i < w) ? (m.c0 + i) : st[i];
-        v[i * KT + t] = live ? X[row * nrhs + tt] : 0.0;
+        v[i * KT + t] = load_if(X, row * nrhs + tt, live);
     }
     __syncthreads();
     // pivot rows minus the part that multiplies already-known ancestors
@@ -559,19 +642,18 @@ static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g
         hipLaunchKernelGGL(k_big_gather, dim3(gx, batch, g.count), dim3(256), 0, st, D.fdesc, g.first,
                            D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool, D.nnz_a, D.pool_size);
         CS3_LAUNCH_CHECK();
-        for (int kb = 0; kb < g.max_w; kb += BIG_NB) {
-            // a front narrower than kb + BIG_NB ends its panel early, so size for the largest remainder
-            const int below = g.max_r - std::min(kb + 1, g.max_r);
-            const int px = std::max(1, (2 * below + 63) / 64);
-            hipLaunchKernelGGL((k_big_panel<KIND>), dim3(px, batch, g.count), dim3(64), 0, st, D.fdesc, g.first, kb,
-                               D.pool, D.pool_size, inv_tol, D.status);
+        // one launch per block of BIG_NB pivots, plus the closing launch (last update + parked blocks)
+        const int nblk = (g.max_w + BIG_NB - 1) / BIG_NB;
+        for (int blk = 0; blk <= nblk; ++blk) {
+            const int kb = blk * BIG_NB;
+            // trailing region starts at ke >= kb + 1 for a front with a panel here, and at
+            // w >= kb - BIG_NB + 1 for a front whose closing launch this is
+            const int start = std::max(1, kb - BIG_NB + 1);
+            const int rem = g.max_r - std::min(start, g.max_r);        // largest trailing order over the group
+            const int tiles = 1 + (rem + 63) / 64;
+            hipLaunchKernelGGL((k_big_step<KIND>), dim3(tiles, tiles, g.count * batch), dim3(256), 0, st, D.fdesc,
+                               g.first, kb, D.pool, D.pool_size, D.dbuf, D.dbuf_size, inv_tol, D.status, (int) batch);
             CS3_LAUNCH_CHECK();
-            const int tiles = (below + 63) / 64;
-            if (tiles > 0) {
-                hipLaunchKernelGGL((k_big_update<KIND>), dim3(tiles, tiles, g.count * batch), dim3(256), 0, st,
-                                   D.fdesc, g.first, kb, D.pool, D.pool_size, (int) batch);
-                CS3_LAUNCH_CHECK();
-            }
         }
         return hipSuccess;
     }

@@ -230,3 +230,17 @@ def spd_grid_matrix(n, ei, ej, seed, shift=1e-2, lower_only=False):
         cols = np.concatenate([ei, ej, np.arange(n)])
         vals = np.concatenate([-w, -w, diag])
     return _coo_to_sorted_csc(n, rows, cols, vals)
+
+
+def dense_block_matrix(n=700, nd=300, seed=1):
+    """Sparse matrix with an embedded nd x nd dense block: its factorisation ends in
+    fronts too large for the LDS, which exercises the blocked big-front kernels.
+    Structurally symmetric, diagonally dominant.  -> (m, n, Ap, Ai, Ax)"""
+    rng = np.random.default_rng(seed)
+    nz = 3 * n
+    ei = rng.integers(0, n, size=nz)
+    ej = rng.integers(0, n, size=nz)
+    idx = rng.choice(n, size=nd, replace=False)
+    bi, bj = np.meshgrid(idx, idx, indexing="ij")
+    ei, ej = _unique_edges(n, np.concatenate([ei, bi.ravel()]), np.concatenate([ej, bj.ravel()]))
+    return _graph_to_matrix(n, ei, ej, rng)

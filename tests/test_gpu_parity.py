@@ -21,6 +21,8 @@ def _cases():
     yield "jacobian118", synth.jacobian_like()
     yield "grid2k", synth.grid_jacobian(n=2000, seed=7)
     yield "grid20k", synth.grid_jacobian(n=20000, seed=11)
+    yield "denseblock300", synth.dense_block_matrix(n=700, nd=300, seed=1)      # fronts beyond the LDS
+    yield "denseblock150", synth.dense_block_matrix(n=400, nd=150, seed=2)
 
 
 CASES = dict(_cases())

@@ -103,7 +103,23 @@ int ensure_device(cs3_handle h)
         if (S.sn_class[s] == FC_BIG) { f.dbuf = dbuf_size; dbuf_size += (i64) ((f.w + 31) / 32) * 1024; }
     }
     D.dbuf_size = dbuf_size;
+    std::vector<SolveDesc> sdesc(S.nsuper);
+    for (i32 t = 0; t < S.nsuper; ++t) {
+        const i32 s = S.ssched[t];
+        SolveDesc &f = sdesc[t];
+        f.lpan = S.lpan_off[s]; f.upan = S.upan_off[s]; f.cv = S.cv_off[s]; f.st = S.st_ptr[s];
+        f.fasm_begin = S.fasm_ptr[s]; f.fasm_count = (int) (S.fasm_ptr[s + 1] - S.fasm_ptr[s]);
+        f.c0 = S.sn_ptr[s];
+        f.r = (int) (S.st_ptr[s + 1] - S.st_ptr[s]);
+        f.w = S.sn_ptr[s + 1] - S.sn_ptr[s];
+        f.u_sk = S.u_sk[s]; f.u_sj = S.u_sj[s];
+        f.parent = S.sn_parent[s];
+    }
     int rc;
+    if ((rc = upload(&D.sdesc, sdesc))) return rc;
+    if ((rc = upload(&D.fasm_src, S.fasm_src))) return rc;
+    if ((rc = upload(&D.fasm_tgt, S.fasm_tgt))) return rc;
+    if ((rc = upload(&D.flong_src, S.flong_src))) return rc;
     if ((rc = upload(&D.meta, meta))) return rc;
     if ((rc = upload(&D.fdesc, fdesc))) return rc;
     if ((rc = upload(&D.sched, S.sched))) return rc;
@@ -216,21 +232,21 @@ int run_solve(cs3_handle h, double *x_dev, long long k, int mode, hipStream_t st
             if (it == h->solve_graphs.end()) {
                 hipGraphExec_t exec = nullptr;
                 rc = capture(h, &exec, [&](hipStream_t cs) {
-                    hipError_t e = launch_solve_levels(D, h->S.groups, D.xp, nrhs, true, cs);
+                    hipError_t e = launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, true, cs);
                     if (e != hipSuccess) return e;
-                    return launch_solve_levels(D, h->S.groups, D.xp, nrhs, false, cs);
+                    return launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, false, cs);
                 });
                 if (rc) return rc;
                 it = h->solve_graphs.emplace(nrhs, exec).first;
             }
             CS3_HIP(hipGraphLaunch(it->second, st));
         } else {
-            CS3_HIP(launch_solve_levels(D, h->S.groups, D.xp, nrhs, true, st));
-            CS3_HIP(launch_solve_levels(D, h->S.groups, D.xp, nrhs, false, st));
+            CS3_HIP(launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, true, st));
+            CS3_HIP(launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, false, st));
         }
         CS3_HIP(launch_permute(D, D.xp, x_dev, nrhs, true, st));
     } else {
-        CS3_HIP(launch_solve_levels(D, h->S.groups, x_dev, nrhs, mode == 1, st));
+        CS3_HIP(launch_solve_levels(D, h->S.sgroups, x_dev, nrhs, mode == 1, st));
     }
     return CS3_OK;
 }
@@ -326,7 +342,7 @@ int cs3_free(cs3_handle h)
         drop_solve_graphs(h);
         if (h->cap_stream) (void) hipStreamDestroy(h->cap_stream);
         void *ptrs[] = {D.meta, D.fdesc, D.sched, D.child_idx, D.rel_idx, D.st_idx, D.asm_src, D.asm_tgt, D.long_src,
-                        D.q, D.ax, D.pool, D.dbuf, D.cv, D.xp, D.status, h->d_lmap, h->d_umap, h->d_lx, h->d_ux};
+                        D.sdesc, D.fasm_src, D.fasm_tgt, D.flong_src, D.q, D.ax, D.pool, D.dbuf, D.cv, D.xp, D.status, h->d_lmap, h->d_umap, h->d_lx, h->d_ux};
         for (void *p : ptrs) if (p) (void) hipFree(p);
     }
     delete h;

@@ -31,6 +31,15 @@ struct FrontDesc {
     int parent;
 };
 
+// What the solve kernels read per front, in SOLVE-schedule order.
+struct SolveDesc {
+    long long lpan, upan, cv, st, fasm_begin;
+    int fasm_count;
+    int c0, r, w;
+    int u_sk, u_sj;               // U(k, j) = pool[upan + k*u_sk + (j-w)*u_sj]
+    int parent;
+};
+
 // Everything the kernels read, resident in HBM for the life of the handle.
 struct DeviceFactor {
     int kind = CS3_LU;
@@ -41,6 +50,8 @@ struct DeviceFactor {
     FrontDesc *fdesc = nullptr;
     int *sched = nullptr, *child_idx = nullptr, *rel_idx = nullptr, *st_idx = nullptr;
     int *asm_src = nullptr, *asm_tgt = nullptr, *long_src = nullptr;
+    SolveDesc *sdesc = nullptr;
+    int *fasm_src = nullptr, *fasm_tgt = nullptr, *flong_src = nullptr;
     int *q = nullptr;             // [n] pivot order
     double *ax = nullptr;         // [batch][nnz_a] values of A (stable address for the graph)
     double *pool = nullptr;       // [batch][pool_size]  factors | contribution blocks

@@ -75,6 +75,14 @@ struct Symbolic {
     std::vector<i64> asm_ptr;                 // [nsuper+1]
     std::vector<i32> asm_src, asm_tgt;
     std::vector<i32> long_src;                // sources of runs longer than 64
+    // forward solve: front vector entry = sum of its sources, same encoding
+    // (src >= 0: entry of the contribution-vector pool; src < 0: row ~src of X)
+    std::vector<i64> fasm_ptr;
+    std::vector<i32> fasm_src, fasm_tgt, flong_src;
+    // solve schedule: supernodes by (level, kind); kind 0 = one wave per front
+    // (r <= 128, w <= 64), kind 1 = one workgroup per front
+    std::vector<i32> ssched;
+    std::vector<LaunchGroup> sgroups;
     // schedule
     i32 nlevels = 0;
     std::vector<i32> sched;                   // supernode ids grouped by (level, class)

@@ -43,20 +43,16 @@ constexpr int ASM_DUMMY_T = 0x3fffffff;
 constexpr int ASM_LONG_T = 0x40000000;
 constexpr int GATHER_UNROLL = 4;
 
-__device__ __forceinline__ double gather_value(int t, int s, int s_next, const double *__restrict__ pool,
-                                               const double *__restrict__ ax, const int *__restrict__ long_src)
+// Fetch(s) returns the address of source s (an unconditional load keeps loads in flight).
+template <class Fetch>
+__device__ __forceinline__ double gather_value(int t, int s, int s_next, const int *__restrict__ long_src, Fetch fetch)
 {
     const bool is_long = (t & ASM_LONG_T) != 0 && t != ASM_DUMMY_T;
     const bool plain = !is_long && t != ASM_DUMMY_T;
-    const int sp = plain ? s : 0;
-    const double *src = (sp >= 0) ? pool + sp : ax + ~sp;      // one unconditional load per entry
-    double v = *src;
+    double v = *fetch(plain ? s : 0);
     if (!plain) v = 0.0;
     if (is_long) {                              // rare: more than 64 sources for one entry
-        for (int k = 0; k < s_next; ++k) {
-            const int q = long_src[s + k];
-            v += (q >= 0) ? pool[q] : ax[~q];
-        }
+        for (int k = 0; k < s_next; ++k) v += *fetch(long_src[s + k]);
     }
     return v;
 }
@@ -81,11 +77,10 @@ __device__ __forceinline__ bool run_totals(int t, double &v)
 }
 
 // Store(t, v) is called once per assembled entry.
-template <int THREADS, class Store>
+template <class Fetch, class Store>
 __device__ __forceinline__ void gather_front(long long asm_begin, int nchunks, int chunk_first, int chunk_stride,
                                              const int *__restrict__ asm_src, const int *__restrict__ asm_tgt,
-                                             const int *__restrict__ long_src, const double *__restrict__ pool,
-                                             const double *__restrict__ ax, Store store)
+                                             const int *__restrict__ long_src, Fetch fetch, Store store)
 {
     const int lane = threadIdx.x & 63;
     for (int c0 = chunk_first; c0 < nchunks; c0 += chunk_stride) {
@@ -102,7 +97,7 @@ __device__ __forceinline__ void gather_front(long long asm_begin, int nchunks, i
 #pragma unroll
         for (int u = 0; u < GATHER_UNROLL; ++u) {
             const int s_next = __shfl_down(s[u], 1);
-            v[u] = gather_value(t[u], s[u], s_next, pool, ax, long_src);
+            v[u] = gather_value(t[u], s[u], s_next, long_src, fetch);
         }
 #pragma unroll
         for (int u = 0; u < GATHER_UNROLL; ++u) {
@@ -141,9 +136,10 @@ k_front_lds(const FrontDesc *__restrict__ fdesc, int first,
     // ---- assemble: F = sum of sources (A entries, children's contribution blocks)
     for (int i = tid; i < r * ld; i += THREADS) F[i] = 0.0;
     __syncthreads();
-    gather_front<THREADS>(d.asm_begin, d.asm_count >> 6, (tid >> 6) * GATHER_UNROLL, (THREADS / 64) * GATHER_UNROLL,
-                          asm_src, asm_tgt, long_src, pool, ax,
-                          [&](int t, double v) { F[t] = v; });
+    gather_front(d.asm_begin, d.asm_count >> 6, (tid >> 6) * GATHER_UNROLL, (THREADS / 64) * GATHER_UNROLL,
+                 asm_src, asm_tgt, long_src,
+                 [&](int q) -> const double * { return (q >= 0) ? pool + q : ax + ~q; },
+                 [&](int t, double v) { F[t] = v; });
     __syncthreads();
 
     // ---- eliminate the w pivots (right-looking inside the front)
@@ -213,9 +209,10 @@ k_big_gather(const FrontDesc *__restrict__ fdesc, int first,
     const double *ax = ax_all + (long long) blockIdx.y * nnz_a;
     double *pool = pool_all + (long long) blockIdx.y * pool_stride;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    gather_front<256>(d.asm_begin, d.asm_count >> 6, wave * GATHER_UNROLL, gridDim.x * 4 * GATHER_UNROLL,
-                      asm_src, asm_tgt, long_src, pool, ax,
-                      [&](int t, double v) { pool[t] = v; });
+    gather_front(d.asm_begin, d.asm_count >> 6, wave * GATHER_UNROLL, gridDim.x * 4 * GATHER_UNROLL,
+                 asm_src, asm_tgt, long_src,
+                 [&](int q) -> const double * { return (q >= 0) ? pool + q : ax + ~q; },
+                 [&](int t, double v) { pool[t] = v; });
 }
 
 // Blocked right-looking LU / Cholesky with ONE launch per block step.
@@ -447,106 +444,283 @@ k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__res
 }
 
 // ------------------------------------------------------ supernodal solves --
-// X is [n, nrhs] row-major in pivot order.  Each block owns one front and one
-// tile of KT right-hand sides (blockIdx.z); lane t of a row handles rhs t.
-template <int KIND, int THREADS>
-__global__ void __launch_bounds__(THREADS)
-k_solve_fwd(const FrontMeta *__restrict__ meta, const int *__restrict__ sched, int first,
-            const int *__restrict__ child_idx, const int *__restrict__ rel_idx,
-            const double *__restrict__ pool_all, double *__restrict__ cv_all, double *__restrict__ X_all,
-            int nrhs, int KT, long long pool_stride, long long cv_stride, long long x_stride)
-{
-    extern __shared__ __attribute__((aligned(16))) double v[];
-    const int s = sched[first + blockIdx.x];
-    const FrontMeta m = meta[s];
-    const double *vals = pool_all + (long long) blockIdx.y * pool_stride;
-    double *cvp = cv_all + (long long) blockIdx.y * cv_stride;
-    double *X = X_all + (long long) blockIdx.y * x_stride;
-    const int r = m.r, w = m.w;
-    const int tid = threadIdx.x, t = tid % KT, i0 = tid / KT, IS = THREADS / KT;
-    const int tt = blockIdx.z * KT + t;
-    const bool live = tt < nrhs;
-    const double *L = vals + m.lpan;
+// X is [n, nrhs] row-major in pivot order; blockIdx.z = right-hand side,
+// blockIdx.y = matrix of the batch.
+//   forward  (L y = b):  front vector v = [X rows of my pivots ; 0] + children's
+//       contribution vectors (gather list), then column by column
+//       y_k = v_k (/ L_kk for Cholesky), v_i -= L_ik y_k for every row i > k of the
+//       front; pivot rows go back to X, the rest is my contribution vector.
+//   backward (U x = y):  v = [X rows of my pivots ; X rows of my ancestors],
+//       pivot rows minus U12 times the ancestors, then back substitution with U11.
+// Panel columns are prefetched SOLVE_PF at a time so that a column step never
+// waits on memory by itself.
+constexpr int SOLVE_PF = 8;
 
-    for (int i = i0; i < r; i += IS)
-        v[i * KT + t] = load_if(X, (long long) (m.c0 + i) * nrhs + tt, i < w && live);
-    __syncthreads();
-    for (int cp = m.child_begin; cp < m.child_end; ++cp) {
-        const FrontMeta mc = meta[child_idx[cp]];
-        const int nbc = mc.r - mc.w;
-        const int *rel = rel_idx + mc.rel;
-        const double *cv = cvp + mc.cv * nrhs;
-        if (live)
-            for (int i = i0; i < nbc; i += IS) v[rel[i] * KT + t] += cv[(long long) i * nrhs + tt];
-        __syncthreads();
-    }
-    for (int k = 0; k < w; ++k) {
-        if (KIND == CS3_CHOLESKY) {
-            if (i0 == 0) v[k * KT + t] /= L[k + (long long) k * r];
-            __syncthreads();
+__device__ __forceinline__ double bcast_lane(double x, int k)     // k wave-uniform
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), k);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), k);
+    return __hiloint2double(hi, lo);
+}
+
+// One wave per front (r <= 128, w <= 64): lane l owns rows l and l + 64.
+template <int KIND>
+__global__ void __launch_bounds__(256)
+k_fwd_wave(const SolveDesc *__restrict__ sd, int first, int count,
+           const int *__restrict__ fsrc, const int *__restrict__ ftgt, const int *__restrict__ flong,
+           const double *__restrict__ pool_all, double *__restrict__ cv_all, double *__restrict__ X_all,
+           int nrhs, long long pool_stride, long long cv_stride, long long x_stride)
+{
+    __shared__ double vs[4][132];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int task = blockIdx.x * 4 + wv;
+    if (task >= count) return;
+    const SolveDesc d = sd[first + task];
+    const int rhs = blockIdx.z;
+    const double *pool = pool_all + (long long) blockIdx.y * pool_stride;
+    double *cv = cv_all + (long long) blockIdx.y * cv_stride;
+    double *X = X_all + (long long) blockIdx.y * x_stride;
+    const int r = d.r, w = d.w;
+    double *v = vs[wv];
+    v[lane] = 0.0; v[lane + 64] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+    gather_front(d.fasm_begin, d.fasm_count >> 6, 0, GATHER_UNROLL, fsrc, ftgt, flong,
+                 [&](int q) -> const double * {
+                     return (q >= 0) ? cv + (long long) q * nrhs + rhs : X + (long long) (~q) * nrhs + rhs;
+                 },
+                 [&](int t, double val) { v[t] = val; });
+    __builtin_amdgcn_wave_barrier();
+    double v0 = v[lane], v1 = v[lane + 64];
+    const double *L = pool + d.lpan;
+    for (int k0 = 0; k0 < w; k0 += SOLVE_PF) {
+        double l0[SOLVE_PF], l1[SOLVE_PF];
+#pragma unroll
+        for (int j = 0; j < SOLVE_PF; ++j) {
+            const int k = k0 + j;
+            l0[j] = load_if(L, lane + (long long) k * r, k < w && lane < r && lane >= k);
+            l1[j] = load_if(L, lane + 64 + (long long) k * r, k < w && lane + 64 < r);
         }
-        const double xk = v[k * KT + t];
-        for (int i = k + 1 + i0; i < r; i += IS) v[i * KT + t] -= L[i + (long long) k * r] * xk;
-        __syncthreads();
-    }
-    if (live) {
-        for (int i = i0; i < w; i += IS) X[(long long) (m.c0 + i) * nrhs + tt] = v[i * KT + t];
-        if (m.parent >= 0) {
-            double *cv = cvp + m.cv * nrhs;
-            for (int i = w + i0; i < r; i += IS) cv[(long long) (i - w) * nrhs + tt] = v[i * KT + t];
+#pragma unroll
+        for (int j = 0; j < SOLVE_PF; ++j) {
+            const int k = k0 + j;
+            if (k < w) {
+                if (KIND == CS3_CHOLESKY && lane == k) v0 /= l0[j];
+                const double xk = bcast_lane(v0, k);
+                if (lane > k) v0 -= l0[j] * xk;
+                v1 -= l1[j] * xk;
+            }
         }
+    }
+    if (lane < w) X[(long long) (d.c0 + lane) * nrhs + rhs] = v0;
+    if (d.parent >= 0) {
+        if (lane >= w && lane < r) cv[(d.cv + lane - w) * nrhs + rhs] = v0;
+        if (lane + 64 < r) cv[(d.cv + lane + 64 - w) * nrhs + rhs] = v1;
     }
 }
 
-template <int KIND, int THREADS>
-__global__ void __launch_bounds__(THREADS)
-k_solve_bwd(const FrontMeta *__restrict__ meta, const int *__restrict__ sched, int first,
-            const int *__restrict__ st_idx, const double *__restrict__ pool_all,
-            double *__restrict__ X_all, int nrhs, int KT, long long pool_stride, long long x_stride)
+template <int KIND>
+__global__ void __launch_bounds__(256)
+k_bwd_wave(const SolveDesc *__restrict__ sd, int first, int count, const int *__restrict__ st_idx,
+           const double *__restrict__ pool_all, double *__restrict__ X_all,
+           int nrhs, long long pool_stride, long long x_stride)
 {
-    extern __shared__ __attribute__((aligned(16))) double v[];
-    const int s = sched[first + blockIdx.x];
-    const FrontMeta m = meta[s];
-    const double *vals = pool_all + (long long) blockIdx.y * pool_stride;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int task = blockIdx.x * 4 + wv;
+    if (task >= count) return;
+    const SolveDesc d = sd[first + task];
+    const int rhs = blockIdx.z;
+    const double *pool = pool_all + (long long) blockIdx.y * pool_stride;
     double *X = X_all + (long long) blockIdx.y * x_stride;
-    const int r = m.r, w = m.w, nb = r - w;
-    const int tid = threadIdx.x, t = tid % KT, i0 = tid / KT, IS = THREADS / KT;
-    const int tt = blockIdx.z * KT + t;
-    const bool live = tt < nrhs;
-    const double *L = vals + m.lpan;
-    const double *U = vals + m.upan;
-    const int *st = st_idx + m.st;
+    const int r = d.r, w = d.w;
+    const int *st = st_idx + d.st;
+    const int i1 = lane + 64;
+    const int row0 = (lane < w) ? d.c0 + lane : st[lane < r ? lane : 0];
+    const int row1 = st[i1 < r ? i1 : 0];
+    double v0 = load_if(X, (long long) row0 * nrhs + rhs, lane < r);
+    const double v1 = load_if(X, (long long) row1 * nrhs + rhs, i1 < r);
+    const double *L = pool + d.lpan;
+    const double *U = pool + d.upan;
+    // pivot row `lane` minus U(lane, k) x_k over the ancestors k = w .. r-1
+    for (int k0 = w; k0 < r; k0 += SOLVE_PF) {
+        double u[SOLVE_PF];
+#pragma unroll
+        for (int j = 0; j < SOLVE_PF; ++j) {
+            const int k = k0 + j;
+            const long long off = (KIND == CS3_LU) ? (long long) lane * d.u_sk + (long long) (k - w) * d.u_sj
+                                                   : (long long) k + (long long) lane * r;
+            u[j] = load_if((KIND == CS3_LU) ? U : L, off, k < r && lane < w);
+        }
+#pragma unroll
+        for (int j = 0; j < SOLVE_PF; ++j) {
+            const int k = k0 + j;
+            if (k < r) {
+                const double xk = (k < 64) ? bcast_lane(v0, k) : bcast_lane(v1, k - 64);
+                v0 -= u[j] * xk;
+            }
+        }
+    }
+    // back substitution with U11, columns w-1 .. 0
+    for (int k0 = w - 1; k0 >= 0; k0 -= SOLVE_PF) {
+        double u[SOLVE_PF];
+#pragma unroll
+        for (int j = 0; j < SOLVE_PF; ++j) {
+            const int k = k0 - j;
+            const long long off = (KIND == CS3_LU) ? (long long) lane + (long long) k * r
+                                                   : (long long) k + (long long) lane * r;
+            u[j] = load_if(L, off, k >= 0 && lane <= k);
+        }
+#pragma unroll
+        for (int j = 0; j < SOLVE_PF; ++j) {
+            const int k = k0 - j;
+            if (k >= 0) {
+                if (lane == k) v0 /= u[j];
+                const double xk = bcast_lane(v0, k);
+                if (lane < k) v0 -= u[j] * xk;
+            }
+        }
+    }
+    if (lane < w) X[(long long) (d.c0 + lane) * nrhs + rhs] = v0;
+}
 
-    for (int i = i0; i < r; i += IS) {
-        const long long row = (i < w) ? (m.c0 + i) : st[i];
-        v[i * KT + t] = load_if(X, row * nrhs + tt, live);
+// One workgroup per front (any size): the front vector lives in LDS, the pivot
+// block is walked in chunks of 64 columns -- wave 0 solves the 64 x 64 triangle
+// with every lane owning one row (whole row prefetched, shuffles for y_k), then
+// all threads apply the chunk to the rows below (one row per thread, 64 loads
+// in flight).
+constexpr int SOLVE_BW = 64;
+
+template <int KIND>
+__global__ void __launch_bounds__(256)
+k_fwd_blk(const SolveDesc *__restrict__ sd, int first,
+          const int *__restrict__ fsrc, const int *__restrict__ ftgt, const int *__restrict__ flong,
+          const double *__restrict__ pool_all, double *__restrict__ cv_all, double *__restrict__ X_all,
+          int nrhs, long long pool_stride, long long cv_stride, long long x_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) double v[];       // [r + 1] then y[64]
+    const SolveDesc d = sd[first + blockIdx.x];
+    const int rhs = blockIdx.z;
+    const double *pool = pool_all + (long long) blockIdx.y * pool_stride;
+    double *cv = cv_all + (long long) blockIdx.y * cv_stride;
+    double *X = X_all + (long long) blockIdx.y * x_stride;
+    const int r = d.r, w = d.w;
+    const int tid = threadIdx.x, lane = tid & 63;
+    double *y = v + r + 1;
+    for (int i = tid; i < r; i += 256) v[i] = 0.0;
+    __syncthreads();
+    gather_front(d.fasm_begin, d.fasm_count >> 6, (tid >> 6) * GATHER_UNROLL, 4 * GATHER_UNROLL, fsrc, ftgt, flong,
+                 [&](int q) -> const double * {
+                     return (q >= 0) ? cv + (long long) q * nrhs + rhs : X + (long long) (~q) * nrhs + rhs;
+                 },
+                 [&](int t, double val) { v[t] = val; });
+    __syncthreads();
+    const double *L = pool + d.lpan;
+    for (int kb = 0; kb < w; kb += SOLVE_BW) {
+        const int bw = min(SOLVE_BW, w - kb);
+        if (tid < 64) {                            // triangle [kb, kb + bw): lane = row kb + lane
+            const int i = kb + lane;
+            double lrow[SOLVE_BW];
+#pragma unroll
+            for (int j = 0; j < SOLVE_BW; ++j)
+                lrow[j] = load_if(L, i + (long long) (kb + j) * r, j < bw && lane < bw && lane >= j);
+            double vi = (lane < bw) ? v[i] : 0.0;
+#pragma unroll
+            for (int j = 0; j < SOLVE_BW; ++j) {
+                if (j < bw) {
+                    if (KIND == CS3_CHOLESKY && lane == j) vi /= lrow[j];
+                    const double xk = bcast_lane(vi, j);
+                    if (lane > j) vi -= lrow[j] * xk;
+                }
+            }
+            if (lane < bw) { v[i] = vi; y[lane] = vi; }
+        }
+        __syncthreads();
+        for (int i = kb + bw + tid; i < r; i += 256) {      // rows below the chunk
+            double acc = 0.0;
+#pragma unroll 16
+            for (int j = 0; j < SOLVE_BW; ++j)
+                acc += load_if(L, i + (long long) (kb + j) * r, j < bw) * y[j];
+            v[i] -= acc;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < w; i += 256) X[(long long) (d.c0 + i) * nrhs + rhs] = v[i];
+    if (d.parent >= 0)
+        for (int i = w + tid; i < r; i += 256) cv[(d.cv + i - w) * nrhs + rhs] = v[i];
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256)
+k_bwd_blk(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ st_idx,
+          const double *__restrict__ pool_all, double *__restrict__ X_all,
+          int nrhs, long long pool_stride, long long x_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) double v[];       // [r + 1] then y[64]
+    const SolveDesc d = sd[first + blockIdx.x];
+    const int rhs = blockIdx.z;
+    const double *pool = pool_all + (long long) blockIdx.y * pool_stride;
+    double *X = X_all + (long long) blockIdx.y * x_stride;
+    const int r = d.r, w = d.w, nb = r - w;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int *st = st_idx + d.st;
+    double *y = v + r + 1;
+    for (int i = tid; i < r; i += 256) {
+        const long long row = (i < w) ? d.c0 + i : st[i];
+        v[i] = X[row * nrhs + rhs];
     }
     __syncthreads();
-    // pivot rows minus the part that multiplies already-known ancestors
-    for (int k = i0; k < w; k += IS) {
+    const double *L = pool + d.lpan;
+    const double *U = pool + d.upan;
+    // v1 -= U12 v2: one wave per pivot row, lanes across the ancestors, fixed-order reduction
+    for (int i = wv; i < w; i += 4) {
         double acc = 0.0;
-        if (KIND == CS3_LU) {
-            const double *u = U + (long long) k * m.u_sk;
-            for (int j = 0; j < nb; ++j) acc += u[(long long) j * m.u_sj] * v[(w + j) * KT + t];
-        } else {
-            const double *l = L + (long long) k * r + w;
-            for (int j = 0; j < nb; ++j) acc += l[j] * v[(w + j) * KT + t];
+        for (int j = lane; j < nb; j += 64) {
+            const double u = (KIND == CS3_LU) ? U[(long long) i * d.u_sk + (long long) j * d.u_sj]
+                                              : L[(long long) (w + j) + (long long) i * r];
+            acc += u * v[w + j];
         }
-        v[k * KT + t] -= acc;
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (lane == 0) v[i] -= acc;
     }
     __syncthreads();
-    for (int k = w - 1; k >= 0; --k) {
-        if (i0 == 0) v[k * KT + t] /= L[k + (long long) k * r];
+    // back substitution, chunks of 64 columns from the right
+    const int nchunk = (w + SOLVE_BW - 1) / SOLVE_BW;
+    for (int c = nchunk - 1; c >= 0; --c) {
+        const int kb = c * SOLVE_BW, bw = min(SOLVE_BW, w - kb);
+        if (tid < 64) {                            // triangle: lane = row kb + lane, columns kb + bw - 1 .. kb
+            const int i = kb + lane;
+            double urow[SOLVE_BW];
+#pragma unroll
+            for (int j = 0; j < SOLVE_BW; ++j) {
+                const long long off = (KIND == CS3_LU) ? (long long) i + (long long) (kb + j) * r
+                                                       : (long long) (kb + j) + (long long) i * r;
+                urow[j] = load_if(L, off, j < bw && lane < bw && lane <= j);
+            }
+            double vi = (lane < bw) ? v[i] : 0.0;
+#pragma unroll
+            for (int jj = 0; jj < SOLVE_BW; ++jj) {
+                const int j = SOLVE_BW - 1 - jj;
+                if (j < bw) {
+                    if (lane == j) vi /= urow[j];
+                    const double xk = bcast_lane(vi, j);
+                    if (lane < j) vi -= urow[j] * xk;
+                }
+            }
+            if (lane < bw) { v[i] = vi; y[lane] = vi; }
+        }
         __syncthreads();
-        const double xk = v[k * KT + t];
-        for (int i = i0; i < k; i += IS) {
-            const double a = (KIND == CS3_LU) ? L[i + (long long) k * r] : L[k + (long long) i * r];
-            v[i * KT + t] -= a * xk;
+        for (int i = tid; i < kb; i += 256) {      // pivot rows above the chunk
+            double acc = 0.0;
+#pragma unroll 16
+            for (int j = 0; j < SOLVE_BW; ++j) {
+                const long long off = (KIND == CS3_LU) ? (long long) i + (long long) (kb + j) * r
+                                                       : (long long) (kb + j) + (long long) i * r;
+                acc += load_if(L, off, j < bw) * y[j];
+            }
+            v[i] -= acc;
         }
         __syncthreads();
     }
-    if (live)
-        for (int i = i0; i < w; i += IS) X[(long long) (m.c0 + i) * nrhs + tt] = v[i * KT + t];
+    for (int i = tid; i < w; i += 256) X[(long long) (d.c0 + i) * nrhs + rhs] = v[i];
 }
 
 // ----------------------------------------------------------- permutations --
@@ -688,10 +862,8 @@ hipError_t prepare_kernels()
                             hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (e != hipSuccess) return e;
     const void *solve_fns[] = {
-        (const void *) k_solve_fwd<CS3_LU, 256>, (const void *) k_solve_fwd<CS3_CHOLESKY, 256>,
-        (const void *) k_solve_bwd<CS3_LU, 256>, (const void *) k_solve_bwd<CS3_CHOLESKY, 256>,
-        (const void *) k_solve_fwd<CS3_LU, 64>, (const void *) k_solve_fwd<CS3_CHOLESKY, 64>,
-        (const void *) k_solve_bwd<CS3_LU, 64>, (const void *) k_solve_bwd<CS3_CHOLESKY, 64>};
+        (const void *) k_fwd_blk<CS3_LU>, (const void *) k_fwd_blk<CS3_CHOLESKY>,
+        (const void *) k_bwd_blk<CS3_LU>, (const void *) k_bwd_blk<CS3_CHOLESKY>};
     for (const void *f : solve_fns) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, big);
         if (e != hipSuccess) return e;
@@ -715,39 +887,29 @@ hipError_t launch_factor_levels(const DeviceFactor &D, const std::vector<LaunchG
     return hipSuccess;
 }
 
-int solve_rhs_tile(int nrhs)
-{
-    int kt = 1;
-    while (kt < nrhs && kt < 32) kt <<= 1;
-    return kt;
-}
-
 template <int KIND>
 static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g, double *X, int nrhs,
                                      bool forward, hipStream_t st)
 {
-    int KT = solve_rhs_tile(nrhs);
-    while (KT > 1 && (size_t) g.max_r * KT * sizeof(double) > 144 * 1024) KT >>= 1;
-    const unsigned tiles = (unsigned) ((nrhs + KT - 1) / KT);
-    dim3 grid((unsigned) g.count, (unsigned) D.batch, tiles);
-    const size_t lds = (size_t) g.max_r * KT * sizeof(double);
     const long long xs = D.n * (long long) nrhs;
     const long long cvs = D.cv_size * (long long) nrhs;
-    const bool small = (long long) g.max_r * KT <= 64;
-    if (forward) {
-        if (small)
-            hipLaunchKernelGGL((k_solve_fwd<KIND, 64>), grid, dim3(64), lds, st, D.meta, D.sched, g.first,
-                               D.child_idx, D.rel_idx, D.pool, D.cv, X, nrhs, KT, D.pool_size, cvs, xs);
+    if (g.cls == 0) {
+        dim3 grid((unsigned) ((g.count + 3) / 4), (unsigned) D.batch, (unsigned) nrhs);
+        if (forward)
+            hipLaunchKernelGGL((k_fwd_wave<KIND>), grid, dim3(256), 0, st, D.sdesc, g.first, g.count, D.fasm_src,
+                               D.fasm_tgt, D.flong_src, D.pool, D.cv, X, nrhs, D.pool_size, cvs, xs);
         else
-            hipLaunchKernelGGL((k_solve_fwd<KIND, 256>), grid, dim3(256), lds, st, D.meta, D.sched, g.first,
-                               D.child_idx, D.rel_idx, D.pool, D.cv, X, nrhs, KT, D.pool_size, cvs, xs);
+            hipLaunchKernelGGL((k_bwd_wave<KIND>), grid, dim3(256), 0, st, D.sdesc, g.first, g.count, D.st_idx,
+                               D.pool, X, nrhs, D.pool_size, xs);
     } else {
-        if (small)
-            hipLaunchKernelGGL((k_solve_bwd<KIND, 64>), grid, dim3(64), lds, st, D.meta, D.sched, g.first,
-                               D.st_idx, D.pool, X, nrhs, KT, D.pool_size, xs);
+        dim3 grid((unsigned) g.count, (unsigned) D.batch, (unsigned) nrhs);
+        const size_t lds = (size_t) (g.max_r + 1 + SOLVE_BW) * sizeof(double);
+        if (forward)
+            hipLaunchKernelGGL((k_fwd_blk<KIND>), grid, dim3(256), lds, st, D.sdesc, g.first, D.fasm_src,
+                               D.fasm_tgt, D.flong_src, D.pool, D.cv, X, nrhs, D.pool_size, cvs, xs);
         else
-            hipLaunchKernelGGL((k_solve_bwd<KIND, 256>), grid, dim3(256), lds, st, D.meta, D.sched, g.first,
-                               D.st_idx, D.pool, X, nrhs, KT, D.pool_size, xs);
+            hipLaunchKernelGGL((k_bwd_blk<KIND>), grid, dim3(256), lds, st, D.sdesc, g.first, D.st_idx,
+                               D.pool, X, nrhs, D.pool_size, xs);
     }
     CS3_LAUNCH_CHECK();
     return hipSuccess;

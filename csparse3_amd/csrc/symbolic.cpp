@@ -451,6 +451,32 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         return (i32) (ti + tj * (r | 1));
     };
     struct Item { i32 tgt, src; };
+    // append one front's (target-sorted) items so that no run of equal targets crosses a
+    // 64-entry boundary; runs longer than 64 are parked in `lng` behind a two-entry record
+    auto emit_runs = [&](const std::vector<Item> &items, std::vector<i32> &tgt, std::vector<i32> &src,
+                         std::vector<i32> &lng) {
+        const i64 start = (i64) tgt.size();
+        auto pad_to_boundary = [&]() {
+            while (((i64) tgt.size() - start) % 64 != 0) { tgt.push_back(ASM_DUMMY); src.push_back(0); }
+        };
+        for (size_t a0 = 0; a0 < items.size(); ) {
+            size_t a1 = a0;
+            while (a1 < items.size() && items[a1].tgt == items[a0].tgt) ++a1;
+            const i64 len = (i64) (a1 - a0);
+            const i64 pos = ((i64) tgt.size() - start) % 64;
+            if (len > 64) {            // rare: one lane sums the run serially
+                if (pos + 2 > 64) pad_to_boundary();
+                tgt.push_back(items[a0].tgt | ASM_LONG); src.push_back((i32) lng.size());
+                tgt.push_back(ASM_DUMMY); src.push_back((i32) len);
+                for (size_t t = a0; t < a1; ++t) lng.push_back(items[t].src);
+            } else {
+                if (pos + len > 64) pad_to_boundary();
+                for (size_t t = a0; t < a1; ++t) { tgt.push_back(items[t].tgt); src.push_back(items[t].src); }
+            }
+            a0 = a1;
+        }
+        pad_to_boundary();
+    };
     std::vector<std::vector<Item>> from_a(ns);
     bool has_upper = false;
     if (kind == CS3_CHOLESKY)
@@ -490,27 +516,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
                         items.push_back(Item{target_of(s, rel[ii], rel[jj]), (i32) (base + ii + jj * ldc)});
             }
             std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.tgt < b.tgt; });
-            const i64 start = (i64) S.asm_tgt.size();
-            auto pad_to_boundary = [&]() {
-                while (((i64) S.asm_tgt.size() - start) % 64 != 0) { S.asm_tgt.push_back(ASM_DUMMY); S.asm_src.push_back(0); }
-            };
-            for (size_t a0 = 0; a0 < items.size(); ) {
-                size_t a1 = a0;
-                while (a1 < items.size() && items[a1].tgt == items[a0].tgt) ++a1;
-                const i64 len = (i64) (a1 - a0);
-                const i64 pos = ((i64) S.asm_tgt.size() - start) % 64;
-                if (len > 64) {            // rare: one lane sums the run serially
-                    if (pos + 2 > 64) pad_to_boundary();
-                    S.asm_tgt.push_back(items[a0].tgt | ASM_LONG); S.asm_src.push_back((i32) S.long_src.size());
-                    S.asm_tgt.push_back(ASM_DUMMY); S.asm_src.push_back((i32) len);
-                    for (size_t t = a0; t < a1; ++t) S.long_src.push_back(items[t].src);
-                } else {
-                    if (pos + len > 64) pad_to_boundary();
-                    for (size_t t = a0; t < a1; ++t) { S.asm_tgt.push_back(items[t].tgt); S.asm_src.push_back(items[t].src); }
-                }
-                a0 = a1;
-            }
-            pad_to_boundary();
+            emit_runs(items, S.asm_tgt, S.asm_src, S.long_src);
             S.asm_ptr[s + 1] = (i64) S.asm_tgt.size();
         }
     }
@@ -536,6 +542,47 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         }
         g.count = t - g.first;
         S.groups.push_back(g);
+    }
+
+    // ---- 10b. forward-solve gather lists and the solve schedule
+    S.fasm_ptr.assign(ns + 1, 0);
+    S.fasm_src.clear(); S.fasm_tgt.clear(); S.flong_src.clear();
+    {
+        std::vector<Item> items;
+        for (i32 s = 0; s < ns; ++s) {
+            items.clear();
+            const i64 w = width(s);
+            for (i64 i = 0; i < w; ++i) items.push_back(Item{(i32) i, (i32) ~(S.sn_ptr[s] + i)});
+            for (i32 cp = S.child_ptr[s]; cp < S.child_ptr[s + 1]; ++cp) {
+                const i32 c = S.child_idx[cp];
+                const i64 nbc = order_r(c) - width(c);
+                const i32 *rel = S.rel_idx.data() + S.rel_ptr[c];
+                for (i64 ii = 0; ii < nbc; ++ii) items.push_back(Item{rel[ii], (i32) (S.cv_off[c] + ii)});
+            }
+            std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.tgt < b.tgt; });
+            emit_runs(items, S.fasm_tgt, S.fasm_src, S.flong_src);
+            S.fasm_ptr[s + 1] = (i64) S.fasm_tgt.size();
+        }
+    }
+    auto solve_kind = [&](i32 s) { return (order_r(s) <= 128 && width(s) <= 64) ? 0 : 1; };
+    S.ssched.resize(ns);
+    std::iota(S.ssched.begin(), S.ssched.end(), 0);
+    std::stable_sort(S.ssched.begin(), S.ssched.end(), [&](i32 a, i32 b) {
+        if (S.sn_level[a] != S.sn_level[b]) return S.sn_level[a] < S.sn_level[b];
+        return solve_kind(a) < solve_kind(b);
+    });
+    S.sgroups.clear();
+    for (i32 t = 0; t < ns; ) {
+        i32 s = S.ssched[t];
+        LaunchGroup g{S.sn_level[s], solve_kind(s), t, 0, 0, 0, 0};
+        while (t < ns && S.sn_level[S.ssched[t]] == g.level && solve_kind(S.ssched[t]) == g.cls) {
+            const i32 f = S.ssched[t];
+            g.max_r = std::max<i32>(g.max_r, (i32) order_r(f));
+            g.max_w = std::max<i32>(g.max_w, (i32) width(f));
+            ++t;
+        }
+        g.count = t - g.first;
+        S.sgroups.push_back(g);
     }
 
     // ---- 11. factors in CSC form: L diagonal first, U diagonal last.  Only the

@@ -114,10 +114,17 @@ __device__ __forceinline__ void flag_column(int *status, int col)
 }
 
 // ------------------------------------------------- front resident in LDS --
-// THREADS = TX * TY; tx runs down a column (consecutive LDS addresses, no
-// bank conflict), ty across columns.  ld is odd so that row reads (stride ld
-// doubles) spread over all banks.
-template <int KIND, int THREADS, int TX>
+// The front is assembled in LDS (leading dimension r | 1), then every thread
+// takes a fixed block-cyclic set of its entries into registers:
+//   thread (tx, ty) of a TX x TY grid owns F(tx + TX a, ty + TY b), a < RI, b < RJ.
+// Right-looking elimination, pivot k:
+//   1. the owners of row k publish it (urow), the owner of (k,k) is among them
+//   2. the owners of column k divide by the pivot and publish the column (lcol)
+//   3. everyone updates the entries it owns: F(i,j) -= lcol(i) urow(j), i, j > k
+// so per pivot only r + r doubles cross the LDS instead of the whole trailing
+// block being read and written there.  Results go back through the LDS image
+// so that the stores to the panels are row-contiguous.
+template <int KIND, int THREADS, int TX, int RI, int RJ>
 __global__ void __launch_bounds__(THREADS)
 k_front_lds(const FrontDesc *__restrict__ fdesc, int first,
             const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
@@ -132,6 +139,8 @@ k_front_lds(const FrontDesc *__restrict__ fdesc, int first,
     const int r = d.r, w = d.w, nb = r - w;
     const int ld = r | 1;
     const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
+    double *urow = F + r * ld + 1;             // [r]   (entry r * ld is the gather's dummy slot)
+    double *lcol = urow + r;                   // [r]
 
     // ---- assemble: F = sum of sources (A entries, children's contribution blocks)
     for (int i = tid; i < r * ld; i += THREADS) F[i] = 0.0;
@@ -142,33 +151,75 @@ k_front_lds(const FrontDesc *__restrict__ fdesc, int first,
                  [&](int t, double v) { F[t] = v; });
     __syncthreads();
 
-    // ---- eliminate the w pivots (right-looking inside the front)
+    // ---- my entries into registers
+    double R[RI][RJ];
+#pragma unroll
+    for (int b = 0; b < RJ; ++b)
+#pragma unroll
+        for (int a = 0; a < RI; ++a) {
+            const int i = tx + TX * a, j = ty + TY * b;
+            R[a][b] = (i < r && j < r) ? F[i + j * ld] : 0.0;
+        }
+
+    // ---- eliminate the w pivots
     for (int k = 0; k < w; ++k) {
-        const double piv = F[k + k * ld];
-        if (KIND == CS3_LU) {
-            for (int i = k + 1 + tid; i < r; i += THREADS) F[i + k * ld] /= piv;
-            __syncthreads();
-            for (int j = k + 1 + ty; j < r; j += TY) {
-                const double u = F[k + j * ld];
-                for (int i = k + 1 + tx; i < r; i += TX) F[i + j * ld] -= F[i + k * ld] * u;
-            }
-        } else {
-            const double dg = sqrt(piv);
-            for (int i = k + 1 + tid; i < r; i += THREADS) F[i + k * ld] /= dg;
-            __syncthreads();
-            if (tid == 0) F[k + k * ld] = (piv > 0.0) ? dg : -1.0;   // -1 marks "not SPD"
-            for (int j = k + 1 + ty; j < r; j += TY) {
-                const double u = F[j + k * ld];
-                for (int i = j + tx; i < r; i += TX) F[i + j * ld] -= F[i + k * ld] * u;
-            }
+        const int ak = k / TX, txk = k % TX, bk = k / TY, tyk = k % TY;
+        if (tx == txk) {                           // 1. row k (incl. the pivot) -> urow
+#pragma unroll
+            for (int a = 0; a < RI; ++a)
+                if (a == ak) {
+#pragma unroll
+                    for (int b = 0; b < RJ; ++b) {
+                        const int j = ty + TY * b;
+                        if (j >= k && j < r) urow[j] = R[a][b];
+                    }
+                }
         }
         __syncthreads();
+        const double piv = urow[k];
+        const double dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
+        if (ty == tyk) {                           // 2. column k / pivot -> lcol
+#pragma unroll
+            for (int b = 0; b < RJ; ++b)
+                if (b == bk) {
+#pragma unroll
+                    for (int a = 0; a < RI; ++a) {
+                        const int i = tx + TX * a;
+                        if (i > k && i < r) { R[a][b] /= dg; lcol[i] = R[a][b]; }
+                        if (KIND == CS3_CHOLESKY && i == k) R[a][b] = (piv > 0.0) ? dg : -1.0;   // -1: not SPD
+                    }
+                }
+        }
+        __syncthreads();
+        double lv[RI], uv[RJ];                     // 3. rank-1 update of what I own
+#pragma unroll
+        for (int a = 0; a < RI; ++a) { const int i = tx + TX * a; lv[a] = (i > k && i < r) ? lcol[i] : 0.0; }
+#pragma unroll
+        for (int b = 0; b < RJ; ++b) {
+            const int j = ty + TY * b;
+            uv[b] = (j > k && j < r) ? ((KIND == CS3_LU) ? urow[j] : lcol[j]) : 0.0;
+        }
+#pragma unroll
+        for (int a = 0; a < RI; ++a)
+#pragma unroll
+            for (int b = 0; b < RJ; ++b) R[a][b] -= lv[a] * uv[b];
     }
 
-    // ---- write back: factors to the panels, Schur block to the pool
+    // ---- registers -> LDS image -> panels / contribution block
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < RJ; ++b)
+#pragma unroll
+        for (int a = 0; a < RI; ++a) {
+            const int i = tx + TX * a, j = ty + TY * b;
+            if (i < r && j < r) F[i + j * ld] = R[a][b];
+        }
+    __syncthreads();
+    constexpr int WX = (THREADS < 64) ? THREADS : 64, WY = THREADS / WX;    // store mapping: wx down a column
+    const int wx = tid % WX, wy = tid / WX;
     double *L = pool + d.lpan;
-    for (int j = ty; j < w; j += TY) {
-        for (int i = tx; i < r; i += TX) {
+    for (int j = wy; j < w; j += WY) {
+        for (int i = wx; i < r; i += WX) {
             const double v = F[i + j * ld];
             if (KIND == CS3_LU) {
                 if (i > j) { if (!(fabs(v) <= inv_tol)) flag_column(status, d.c0 + j); }
@@ -181,13 +232,13 @@ k_front_lds(const FrontDesc *__restrict__ fdesc, int first,
     }
     if (KIND == CS3_LU) {
         double *U = pool + d.upan;
-        for (int k = ty; k < w; k += TY)
-            for (int i = tx; i < nb; i += TX) U[i + (long long) k * nb] = F[k + (w + i) * ld];
+        for (int k = wy; k < w; k += WY)
+            for (int i = wx; i < nb; i += WX) U[i + (long long) k * nb] = F[k + (w + i) * ld];
     }
     if (d.parent >= 0) {
         double *cb = pool + d.cb;
-        for (int j = ty; j < nb; j += TY)
-            for (int i = tx; i < nb; i += TX)
+        for (int j = wy; j < nb; j += WY)
+            for (int i = wx; i < nb; i += WX)
                 if (KIND == CS3_LU || i >= j) cb[i + (long long) j * nb] = F[(w + i) + (w + j) * ld];
     }
 }
@@ -833,17 +884,17 @@ static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g
     }
     dim3 grid((unsigned) g.count, batch);
     const size_t ld = (size_t) (g.max_r | 1);
-    const size_t lds = ld * (size_t) g.max_r * sizeof(double);
+    const size_t lds = (ld * (size_t) g.max_r + 2 * (size_t) g.max_r + 2) * sizeof(double);
 #define CS3_FRONT_ARGS D.fdesc, g.first, D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool, D.nnz_a, D.pool_size, inv_tol, D.status
     switch (g.cls) {
     case FC_R16:
-        hipLaunchKernelGGL((k_front_lds<KIND, 64, 16>), grid, dim3(64), lds, st, CS3_FRONT_ARGS); break;
+        hipLaunchKernelGGL((k_front_lds<KIND, 64, 8, 2, 2>), grid, dim3(64), lds, st, CS3_FRONT_ARGS); break;
     case FC_R32:
-        hipLaunchKernelGGL((k_front_lds<KIND, 64, 32>), grid, dim3(64), lds, st, CS3_FRONT_ARGS); break;
+        hipLaunchKernelGGL((k_front_lds<KIND, 64, 8, 4, 4>), grid, dim3(64), lds, st, CS3_FRONT_ARGS); break;
     case FC_R64:
-        hipLaunchKernelGGL((k_front_lds<KIND, 256, 64>), grid, dim3(256), lds, st, CS3_FRONT_ARGS); break;
+        hipLaunchKernelGGL((k_front_lds<KIND, 256, 16, 4, 4>), grid, dim3(256), lds, st, CS3_FRONT_ARGS); break;
     default:
-        hipLaunchKernelGGL((k_front_lds<KIND, 512, 64>), grid, dim3(512), lds, st, CS3_FRONT_ARGS); break;
+        hipLaunchKernelGGL((k_front_lds<KIND, 512, 32, 5, 9>), grid, dim3(512), lds, st, CS3_FRONT_ARGS); break;
     }
 #undef CS3_FRONT_ARGS
     CS3_LAUNCH_CHECK();
@@ -855,10 +906,10 @@ hipError_t prepare_kernels()
     // the largest LDS-resident class needs more than the default 64 KiB of dynamic LDS
     const int big = 160 * 1024;
     hipError_t e;
-    e = hipFuncSetAttribute((const void *) k_front_lds<CS3_LU, 512, 64>,
+    e = hipFuncSetAttribute((const void *) k_front_lds<CS3_LU, 512, 32, 5, 9>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void *) k_front_lds<CS3_CHOLESKY, 512, 64>,
+    e = hipFuncSetAttribute((const void *) k_front_lds<CS3_CHOLESKY, 512, 32, 5, 9>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (e != hipSuccess) return e;
     const void *solve_fns[] = {

@@ -134,6 +134,12 @@ int ensure_device(cs3_handle h)
     CS3_HIP(hipMalloc((void **) &D.dbuf, std::max<size_t>(1, (size_t) (D.batch * D.dbuf_size)) * sizeof(double)));
     CS3_HIP(hipMalloc((void **) &D.ax, std::max<size_t>(1, (size_t) (D.batch * D.nnz_a)) * sizeof(double)));
     CS3_HIP(hipMalloc((void **) &D.status, sizeof(int)));
+    if (const char *pf = std::getenv("CS3_PROFILE")) {
+        if (pf[0] == '1') {
+            CS3_HIP(hipMalloc((void **) &D.tbuf, std::max<size_t>(1, (size_t) S.nsuper) * 8 * sizeof(long long)));
+            CS3_HIP(hipMemset(D.tbuf, 0, std::max<size_t>(1, (size_t) S.nsuper) * 8 * sizeof(long long)));
+        }
+    }
     CS3_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
     const char *ng = std::getenv("CS3_NO_GRAPH");
     h->use_graph = !(ng && ng[0] == '1');
@@ -342,7 +348,7 @@ int cs3_free(cs3_handle h)
         drop_solve_graphs(h);
         if (h->cap_stream) (void) hipStreamDestroy(h->cap_stream);
         void *ptrs[] = {D.meta, D.fdesc, D.sched, D.child_idx, D.rel_idx, D.st_idx, D.asm_src, D.asm_tgt, D.long_src,
-                        D.sdesc, D.fasm_src, D.fasm_tgt, D.flong_src, D.q, D.ax, D.pool, D.dbuf, D.cv, D.xp, D.status, h->d_lmap, h->d_umap, h->d_lx, h->d_ux};
+                        D.sdesc, D.fasm_src, D.fasm_tgt, D.flong_src, D.q, D.ax, D.pool, D.dbuf, D.tbuf, D.cv, D.xp, D.status, h->d_lmap, h->d_umap, h->d_lx, h->d_ux};
         for (void *p : ptrs) if (p) (void) hipFree(p);
     }
     delete h;
@@ -453,6 +459,28 @@ int cs3_solve(cs3_handle h, double *X, int64_t k)
     (void) hipFree(d_x);
     if (rc) return rc;
     CS3_HIP(e);
+    return CS3_OK;
+}
+
+int cs3_debug_schedule(cs3_handle h, int32_t *sched, int32_t *front_r, int32_t *front_w)
+{
+    int rc = guard(h); if (rc) return rc;
+    const Symbolic &S = h->S;
+    for (i32 t = 0; t < S.nsuper; ++t) {
+        const i32 s = S.sched[t];
+        if (sched) sched[t] = s;
+        if (front_r) front_r[t] = (i32) (S.st_ptr[s + 1] - S.st_ptr[s]);
+        if (front_w) front_w[t] = S.sn_ptr[s + 1] - S.sn_ptr[s];
+    }
+    return CS3_OK;
+}
+
+int cs3_debug_front_stamps(cs3_handle h, int64_t *out)
+{
+    int rc = guard(h); if (rc) return rc;
+    if (!h->on_device || !h->D.tbuf) { set_error("cs3_debug_front_stamps: run with CS3_PROFILE=1"); return CS3_ERR_STATE; }
+    CS3_HIP(hipDeviceSynchronize());
+    CS3_HIP(hipMemcpy(out, h->D.tbuf, (size_t) h->S.nsuper * 8 * sizeof(long long), hipMemcpyDeviceToHost));
     return CS3_OK;
 }
 

@@ -61,6 +61,7 @@ struct DeviceFactor {
     double *xp = nullptr;         // [batch][n * nrhs_cap] right-hand sides in pivot order
     long long nrhs_cap = 0;
     int *status = nullptr;        // [1] first failing pivot column, 0x7f7f7f7f when clean
+    long long *tbuf = nullptr;    // diagnostics (CS3_PROFILE=1): 8 shader-clock stamps per front, schedule order
 };
 
 hipError_t prepare_kernels();

@@ -129,27 +129,31 @@ __global__ void __launch_bounds__(THREADS)
 k_front_lds(const FrontDesc *__restrict__ fdesc, int first,
             const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
             const double *__restrict__ ax_all, double *__restrict__ pool_all,
-            long long nnz_a, long long pool_stride, double inv_tol, int *status)
+            long long nnz_a, long long pool_stride, double inv_tol, int *status, long long *tbuf)
 {
     extern __shared__ __attribute__((aligned(16))) double F[];
     constexpr int TY = THREADS / TX;
+    const long long t_start = tbuf ? (long long) __builtin_amdgcn_s_memtime() : 0;
     const FrontDesc d = fdesc[first + blockIdx.x];
+#define CS3_STAMP(p) do { if (tbuf && threadIdx.x == 0) tbuf[(long long) (first + blockIdx.x) * 8 + (p)] = (long long) __builtin_amdgcn_s_memtime() - t_start; } while (0)
     const double *ax = ax_all + (long long) blockIdx.y * nnz_a;
     double *pool = pool_all + (long long) blockIdx.y * pool_stride;
     const int r = d.r, w = d.w, nb = r - w;
     const int ld = r | 1;
     const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
-    double *urow = F + r * ld + 1;             // [r]   (entry r * ld is the gather's dummy slot)
-    double *lcol = urow + r;                   // [r]
+    double *urow = F + r * ld + 1;             // [r] pivot row, then [r] scaled pivot column; entry r * ld is the gather's dummy slot
 
     // ---- assemble: F = sum of sources (A entries, children's contribution blocks)
+    CS3_STAMP(0);
     for (int i = tid; i < r * ld; i += THREADS) F[i] = 0.0;
     __syncthreads();
+    CS3_STAMP(1);
     gather_front(d.asm_begin, d.asm_count >> 6, (tid >> 6) * GATHER_UNROLL, (THREADS / 64) * GATHER_UNROLL,
                  asm_src, asm_tgt, long_src,
                  [&](int q) -> const double * { return (q >= 0) ? pool + q : ax + ~q; },
                  [&](int t, double v) { F[t] = v; });
     __syncthreads();
+    CS3_STAMP(2);
 
     // ---- my entries into registers
     double R[RI][RJ];
@@ -161,7 +165,8 @@ k_front_lds(const FrontDesc *__restrict__ fdesc, int first,
             R[a][b] = (i < r && j < r) ? F[i + j * ld] : 0.0;
         }
 
-    // ---- eliminate the w pivots
+    // ---- eliminate the w pivots (two barriers per pivot: row, then scaled column)
+    double *lcol = urow + r;
     for (int k = 0; k < w; ++k) {
         const int ak = k / TX, txk = k % TX, bk = k / TY, tyk = k % TY;
         if (tx == txk) {                           // 1. row k (incl. the pivot) -> urow
@@ -185,8 +190,19 @@ k_front_lds(const FrontDesc *__restrict__ fdesc, int first,
 #pragma unroll
                     for (int a = 0; a < RI; ++a) {
                         const int i = tx + TX * a;
-                        if (i > k && i < r) { R[a][b] /= dg; lcol[i] = R[a][b]; }
-                        if (KIND == CS3_CHOLESKY && i == k) R[a][b] = (piv > 0.0) ? dg : -1.0;   // -1: not SPD
+                        if (i > k && i < r) {
+                            R[a][b] /= dg;
+                            lcol[i] = R[a][b];
+                            if (KIND == CS3_LU && !(fabs(R[a][b]) <= inv_tol)) flag_column(status, d.c0 + k);
+                        }
+                        if (i == k) {
+                            if (KIND == CS3_LU) {
+                                if (!(fabs(piv) > 0.0) || !(fabs(piv) < 1.0e300)) flag_column(status, d.c0 + k);
+                            } else {
+                                R[a][b] = dg;
+                                if (!(piv > 0.0)) flag_column(status, d.c0 + k);
+                            }
+                        }
                     }
                 }
         }
@@ -205,42 +221,30 @@ k_front_lds(const FrontDesc *__restrict__ fdesc, int first,
             for (int b = 0; b < RJ; ++b) R[a][b] -= lv[a] * uv[b];
     }
 
-    // ---- registers -> LDS image -> panels / contribution block
-    __syncthreads();
+    CS3_STAMP(3);
+    CS3_STAMP(4);
+    // ---- store straight from registers: L panel, U panel, contribution block
+    double *L = pool + d.lpan;
+    double *U = pool + d.upan;
+    double *cb = pool + d.cb;
+    const bool has_parent = d.parent >= 0;
 #pragma unroll
     for (int b = 0; b < RJ; ++b)
 #pragma unroll
         for (int a = 0; a < RI; ++a) {
             const int i = tx + TX * a, j = ty + TY * b;
-            if (i < r && j < r) F[i + j * ld] = R[a][b];
-        }
-    __syncthreads();
-    constexpr int WX = (THREADS < 64) ? THREADS : 64, WY = THREADS / WX;    // store mapping: wx down a column
-    const int wx = tid % WX, wy = tid / WX;
-    double *L = pool + d.lpan;
-    for (int j = wy; j < w; j += WY) {
-        for (int i = wx; i < r; i += WX) {
-            const double v = F[i + j * ld];
-            if (KIND == CS3_LU) {
-                if (i > j) { if (!(fabs(v) <= inv_tol)) flag_column(status, d.c0 + j); }
-                else if (i == j) { if (!(fabs(v) > 0.0) || !(fabs(v) < 1.0e300)) flag_column(status, d.c0 + j); }
-            } else if (i == j) {
-                if (!(v > 0.0)) flag_column(status, d.c0 + j);
+            if (i >= r || j >= r) continue;
+            const double v = R[a][b];
+            if (j < w) {
+                if (KIND == CS3_LU || i >= j) L[i + (long long) j * r] = v;
+            } else if (i < w) {
+                if (KIND == CS3_LU) U[(j - w) + (long long) i * nb] = v;
+            } else if (has_parent) {
+                if (KIND == CS3_LU || i >= j) cb[(i - w) + (long long) (j - w) * nb] = v;
             }
-            if (KIND == CS3_LU || i >= j) L[i + (long long) j * r] = v;
         }
-    }
-    if (KIND == CS3_LU) {
-        double *U = pool + d.upan;
-        for (int k = wy; k < w; k += WY)
-            for (int i = wx; i < nb; i += WX) U[i + (long long) k * nb] = F[k + (w + i) * ld];
-    }
-    if (d.parent >= 0) {
-        double *cb = pool + d.cb;
-        for (int j = wy; j < nb; j += WY)
-            for (int i = wx; i < nb; i += WX)
-                if (KIND == CS3_LU || i >= j) cb[i + (long long) j * nb] = F[(w + i) + (w + j) * ld];
-    }
+    CS3_STAMP(5);
+#undef CS3_STAMP
 }
 
 // ------------------------------------------- front too large for the LDS --
@@ -884,8 +888,8 @@ static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g
     }
     dim3 grid((unsigned) g.count, batch);
     const size_t ld = (size_t) (g.max_r | 1);
-    const size_t lds = (ld * (size_t) g.max_r + 2 * (size_t) g.max_r + 2) * sizeof(double);
-#define CS3_FRONT_ARGS D.fdesc, g.first, D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool, D.nnz_a, D.pool_size, inv_tol, D.status
+    const size_t lds = (ld * (size_t) g.max_r + 4 * (size_t) g.max_r + 6) * sizeof(double);
+#define CS3_FRONT_ARGS D.fdesc, g.first, D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool, D.nnz_a, D.pool_size, inv_tol, D.status, D.tbuf
     switch (g.cls) {
     case FC_R16:
         hipLaunchKernelGGL((k_front_lds<KIND, 64, 8, 2, 2>), grid, dim3(64), lds, st, CS3_FRONT_ARGS); break;

@@ -112,7 +112,7 @@ int front_class(i64 r)
     if (r <= 16) return FC_R16;
     if (r <= 32) return FC_R32;
     if (r <= 64) return FC_R64;
-    if (r <= 136) return FC_LDS;      // (136*137 + 2*136) doubles = 151 KB of the 160 KB LDS
+    if (r <= 136) return FC_LDS;      // (136*137 + 4*136 + 6) doubles = 153 KB of the 160 KB LDS
     return FC_BIG;
 }
 

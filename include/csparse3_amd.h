@@ -128,6 +128,15 @@ int cs3_usolve_dev(cs3_handle h, double *X_dev, int64_t k, void *stream);
 int cs3_get_factors(cs3_handle h, int64_t b, int32_t *Lp, int32_t *Li, double *Lx,
                     int32_t *Up, int32_t *Ui, double *Ux);
 
+/* ---- diagnostics --------------------------------------------------------
+ * With CS3_PROFILE=1 in the environment every LDS-resident front records six
+ * shader-clock stamps (descriptor read, zeroed, assembled, eliminated, staged,
+ * stored) relative to its start; out[nsuper][8] in schedule order.  Not part
+ * of the reference-facing surface. */
+int cs3_debug_front_stamps(cs3_handle h, int64_t *out);
+/* Factorisation schedule: supernode id, front order r and width w per schedule slot. */
+int cs3_debug_schedule(cs3_handle h, int32_t *sched, int32_t *front_r, int32_t *front_w);
+
 /* ---- general triangular solves on caller-supplied CSC factors -----------
  * cs_lsolve / cs_usolve lineage, the csc_lsolve_f(n, Lp, Li, Lx, x) shape of
  * x[n, k] row-major, in place; diagonal first (L) /

@@ -71,7 +71,8 @@ def lib():
         L.cs3_factor.argtypes = [vp, _f64p, C.c_double]
         L.cs3_factor_dev.argtypes = [vp, vp, C.c_double, vp]
         L.cs3_factor_status.argtypes = [vp, vp]
-        L.cs3_solve.argtypes = [vp, _f64p, I64]
+        for f in (L.cs3_solve, L.cs3_lsolve, L.cs3_usolve):
+            f.argtypes = [vp, _f64p, I64]
         for f in (L.cs3_solve_dev, L.cs3_lsolve_dev, L.cs3_usolve_dev):
             f.argtypes = [vp, vp, I64, vp]
         L.cs3_get_factors.argtypes = [vp, I64, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p]
@@ -224,6 +225,21 @@ class Factorization:
         assert x.size % per == 0, "right-hand side does not match [batch,] n [, k]"
         _check(lib().cs3_solve(self._h, _pf(x), x.size // per))
         return x
+
+    def _sweep(self, fn, x):
+        x = np.array(x, dtype=np.float64, order="C", copy=True)
+        per = self.batch * self.n
+        assert x.size % per == 0
+        _check(fn(self._h, _pf(x), x.size // per))
+        return x
+
+    def lsolve(self, x):
+        """x = L \\ x in pivot order (cs_lsolve on this factorisation's L)."""
+        return self._sweep(lib().cs3_lsolve, x)
+
+    def usolve(self, x):
+        """x = U \\ x in pivot order (cs_usolve; L' for Cholesky, i.e. cs_ltsolve)."""
+        return self._sweep(lib().cs3_usolve, x)
 
     # -- numeric, device pointers (e.g. torch.Tensor.data_ptr()) on a HIP stream
     def factor_dev(self, ax_ptr, tol=0.0, stream=0):

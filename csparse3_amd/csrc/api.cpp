@@ -443,17 +443,17 @@ int cs3_usolve_dev(cs3_handle h, double *X_dev, int64_t k, void *stream)
     return run_solve(h, X_dev, k, 2, (hipStream_t) stream);
 }
 
-int cs3_solve(cs3_handle h, double *X, int64_t k)
+static int solve_host(cs3_handle h, double *X, int64_t k, int mode)
 {
     int rc = guard(h); if (rc) return rc;
-    if (!X) { set_error("cs3_solve: null right-hand side"); return CS3_ERR_ARG; }
+    if (!X) { set_error("solve: null right-hand side"); return CS3_ERR_ARG; }
     if (!h->factored) { set_error("solve before a successful factorisation"); return CS3_ERR_STATE; }
     const size_t bytes = (size_t) (h->batch * h->S.n * k) * sizeof(double);
     double *d_x = nullptr;
     CS3_HIP(hipMalloc((void **) &d_x, std::max<size_t>(bytes, 8)));
     hipError_t e = hipMemcpy(d_x, X, bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        rc = run_solve(h, d_x, k, 0, nullptr);
+        rc = run_solve(h, d_x, k, mode, nullptr);
         if (rc == CS3_OK) e = hipMemcpy(X, d_x, bytes, hipMemcpyDeviceToHost);
     }
     (void) hipFree(d_x);
@@ -461,6 +461,10 @@ int cs3_solve(cs3_handle h, double *X, int64_t k)
     CS3_HIP(e);
     return CS3_OK;
 }
+
+int cs3_solve(cs3_handle h, double *X, int64_t k) { return solve_host(h, X, k, 0); }
+int cs3_lsolve(cs3_handle h, double *X, int64_t k) { return solve_host(h, X, k, 1); }
+int cs3_usolve(cs3_handle h, double *X, int64_t k) { return solve_host(h, X, k, 2); }
 
 int cs3_debug_schedule(cs3_handle h, int32_t *sched, int32_t *front_r, int32_t *front_w)
 {

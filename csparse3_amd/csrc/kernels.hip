@@ -844,8 +844,11 @@ k_matvec_rows(const int *__restrict__ Rp, const int *__restrict__ Rj,
         const long long i = e / nrhs;
         const int t = (int) (e - i * nrhs);
         double y = 0.0;
-        for (int p = Rp[i]; p < Rp[i + 1]; ++p)
-            y = __dadd_rn(y, __dmul_rn(Rx[p], X[(long long) Rj[p] * nrhs + t]));
+        for (int p = Rp[i]; p < Rp[i + 1]; ++p) {
+#pragma clang fp contract(off)                   // the reference rounds the product, then the sum
+            const double prod = Rx[p] * X[(long long) Rj[p] * nrhs + t];
+            y = y + prod;
+        }
         Y[e] = y;
     }
 }

@@ -116,6 +116,8 @@ int cs3_factor_status(cs3_handle h, void *stream);
  * cs3_lsolve:  x = L \ x     in the permuted (pivot-order) space
  * cs3_usolve:  x = U \ x     (for Cholesky: x = L' \ x) */
 int cs3_solve(cs3_handle h, double *X, int64_t k);
+int cs3_lsolve(cs3_handle h, double *X, int64_t k);
+int cs3_usolve(cs3_handle h, double *X, int64_t k);
 int cs3_solve_dev(cs3_handle h, double *X_dev, int64_t k, void *stream);
 int cs3_lsolve_dev(cs3_handle h, double *X_dev, int64_t k, void *stream);
 int cs3_usolve_dev(cs3_handle h, double *X_dev, int64_t k, void *stream);

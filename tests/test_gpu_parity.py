@@ -56,3 +56,199 @@ def test_lusol_matches_oracle(gpu, orc, name, k):
     A = csc_to_scipy(m, n, Ap, Ai, Ax)
     R = A @ X - B
     assert np.abs(R).max() <= 1e-12 * (abs(A).sum(axis=0).max() * np.abs(X).max() + np.abs(B).max())
+
+
+# --------------------------------------------------------------- Cholesky --
+
+def _spd_cases():
+    for n in (200, 4000):
+        ei, ej = synth.spd_grid_pattern(n, seed=n)
+        yield "spd%d" % n, synth.spd_grid_matrix(n, ei, ej, seed=n + 1)
+    m, n, Ap, Ai, Ax = synth.dense_block_matrix(n=500, nd=220, seed=3)
+    import scipy.sparse as sp
+    A = sp.csc_matrix((Ax, Ai, Ap), shape=(n, n))
+    S = (A + A.T).tocsc(); S.sort_indices()               # symmetric, still diagonally dominant => SPD
+    yield "spd_denseblock", (n, n, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.copy())
+
+
+SPD = dict(_spd_cases())
+
+
+def _oracle_chol(orc, n, Ap, Ai, Ax, q):
+    pinv = orc.csc_pinv(q)
+    _, _, Cp, Ci, _ = orc.csc_symperm(n, Ap, Ai, None, pinv)
+    parent = orc.csc_etree_f(n, Cp, Ci)
+    post = orc.csc_post_f(n, parent)
+    cnt = orc.csc_counts_f(n, Cp, Ci, parent, post)
+    cp = np.zeros(n + 1, dtype=np.int32); cp[1:] = np.cumsum(cnt)
+    return orc.csc_chol_f(n, Ap, Ai, Ax, pinv, parent, cp)
+
+
+@pytest.mark.parametrize("name", list(SPD))
+def test_cholesky_factor_and_solve_match_oracle(gpu, orc, name):
+    m, n, Ap, Ai, Ax = SPD[name]
+    with gpu.Factorization(m, n, Ap, Ai, kind=gpu.CS3_CHOLESKY) as F:
+        F.factor(Ax)
+        Lp, Li, Lx, _, _, _ = F.factors()
+        q = F.ordering()["q"]
+        b = np.random.default_rng(1).standard_normal((n, 3))
+        X = F.solve(b)
+    assert_factor_equal(n, (Lp, Li, Lx), _oracle_chol(orc, n, Ap, Ai, Ax, q), name + " L")
+    A = csc_to_scipy(m, n, Ap, Ai, Ax)
+    assert np.abs(A @ X - b).max() <= 1e-11 * np.abs(b).max() * n
+    # a triangle-only input gives the same factor (cs_chol reads the upper triangle)
+    import scipy.sparse as sp
+    T = sp.triu(A, format="csc"); T.sort_indices()
+    with gpu.Factorization(m, n, T.indptr, T.indices, kind=gpu.CS3_CHOLESKY, q=F_q(q)) as G:
+        G.factor(T.data)
+        Lp2, Li2, Lx2, _, _, _ = G.factors()
+    assert np.array_equal(Lp, Lp2) and np.array_equal(Li, Li2) and rel_err(Lx2, Lx) <= RTOL
+
+
+def F_q(q):
+    return np.asarray(q, dtype=np.int32)
+
+
+def test_cholesky_rejects_indefinite_matrix(gpu):
+    m, n, Ap, Ai, Ax = SPD["spd200"]
+    bad = Ax.copy(); bad[Ap[:-1]] *= -1.0               # first entry of each column ... make the diagonal negative
+    rows = Ai[:Ap[n]]; cols = np.repeat(np.arange(n), np.diff(Ap))
+    bad = Ax.copy(); bad[rows == cols] = -np.abs(bad[rows == cols])
+    with gpu.Factorization(m, n, Ap, Ai, kind=gpu.CS3_CHOLESKY) as F:
+        with pytest.raises(gpu.NotPositiveDefinite):
+            F.factor(bad)
+        assert F.info.fail_col >= 0
+        with pytest.raises(gpu.Cs3Error):
+            F.solve(np.ones(n))                          # no valid factorisation to solve with
+
+
+# ----------------------------------------------------- pivots and failures --
+
+def test_static_pivot_rejection_is_reported(gpu, orc):
+    m, n, Ap, Ai, Ax = CASES["jacobian118"]
+    rows = Ai[:Ap[n]]; cols = np.repeat(np.arange(n), np.diff(Ap))
+    with gpu.Factorization(m, n, Ap, Ai) as F:
+        # a leaf of the elimination tree with entries below the diagonal: its pivot is A's own
+        # diagonal entry, untouched by earlier eliminations
+        Lp, Li = F.factors(values=False)[:2]
+        k0 = next(k for k in range(n) if Lp[k + 1] - Lp[k] > 1 and k not in set(Li[:Lp[k]].tolist()))
+        first = F.ordering()["q"][k0]
+        weak = Ax.copy(); weak[(rows == cols) & (cols == first)] = 1e-9   # fails |pivot| >= tol * max|column|
+        with pytest.raises(gpu.SingularMatrix):
+            F.factor(weak, tol=1e-3)
+        assert F.info.fail_col == k0
+        # the oracle agrees that the diagonal is not acceptable there: it pivots off the diagonal
+        opinv = orc.csc_lu_f(n, n, Ap, Ai, weak, F.ordering()["q"], 1e-3)[6]
+        assert opinv[first] != k0
+        F.factor(weak, tol=0.0)                          # the test can be switched off (cs_lu's tol -> 0)
+        zero = Ax.copy(); zero[(rows == cols) & (cols == first)] = 0.0
+        with pytest.raises(gpu.SingularMatrix):
+            F.factor(zero, tol=0.0)                      # an exactly zero pivot is always an error
+        F.factor(Ax, tol=1e-3)                           # the handle recovers with good values
+        x = F.solve(np.ones(n))
+    A = csc_to_scipy(m, n, Ap, Ai, Ax)
+    assert np.abs(A @ x - 1.0).max() < 1e-10
+
+
+# ------------------------------------------------------------ the sweeps ----
+
+@pytest.mark.parametrize("name", ["jacobian118", "grid20k", "denseblock300"])
+def test_lsolve_usolve_on_the_handle_match_oracle(gpu, orc, name):
+    m, n, Ap, Ai, Ax = CASES[name]
+    rng = np.random.default_rng(4)
+    with gpu.Factorization(m, n, Ap, Ai) as F:
+        F.factor(Ax, 1e-3)
+        Lp, Li, Lx, Up, Ui, Ux = F.factors()
+        b = rng.standard_normal(n)
+        y = F.lsolve(b)
+        x = F.usolve(y)
+    wy = b.copy(); orc.csc_lsolve_f(n, Lp, Li, Lx, wy)
+    wx = wy.copy(); orc.csc_usolve_f(n, Up, Ui, Ux, wx)
+    assert rel_err(y, wy) <= RTOL and rel_err(x, wx) <= RTOL
+
+
+@pytest.mark.parametrize("k", [1, 4])
+def test_general_csc_triangular_solves_match_oracle(gpu, orc, k):
+    """csc_lsolve_f / csc_usolve_f on caller-supplied factors (here: the oracle's own, rows unsorted)."""
+    m, n, Ap, Ai, Ax = CASES["grid2k"]
+    q = orc.csc_amd_f(1, n, n, Ap, Ai)
+    Lp, Li, Lx, Up, Ui, Ux, pinv = orc.csc_lu_f(n, n, Ap, Ai, Ax, q, 1e-3)
+    rng = np.random.default_rng(8)
+    B = rng.standard_normal((n, k)) if k > 1 else rng.standard_normal(n)
+    X = np.ascontiguousarray(B.copy()); gpu.csc_lsolve_f(n, Lp, Li, Lx, X)
+    W = np.ascontiguousarray(B.copy())
+    for t in range(k):
+        col = np.ascontiguousarray(W[:, t]) if k > 1 else W
+        orc.csc_lsolve_f(n, Lp, Li, Lx, col)
+        if k > 1: W[:, t] = col
+    assert rel_err(X, W) <= RTOL
+    gpu.csc_usolve_f(n, Up, Ui, Ux, X)
+    for t in range(k):
+        col = np.ascontiguousarray(W[:, t]) if k > 1 else W
+        orc.csc_usolve_f(n, Up, Ui, Ux, col)
+        if k > 1: W[:, t] = col
+    assert rel_err(X, W) <= RTOL
+
+
+def test_matvec_is_bit_exact_with_the_reference_kernel(gpu):
+    """csc_mat_vec_ff on the device reproduces the reference's own outputs exactly
+    (same summation order, separate multiply and add roundings)."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "substrate.npz"))
+    for tag in ("r1", "r2", "r3"):
+        m, n = int(G[tag + "_m"]), int(G[tag + "_n"])
+        y = gpu.csc_mat_vec_ff(m, n, G[tag + "_Ap"], G[tag + "_Ai"], G[tag + "_Ax"], G[tag + "_x"])
+        assert np.array_equal(y, G[tag + "_matvec"])
+    y = gpu.csc_mat_vec_ff(6, 3, G["doc_Ap"], G["doc_Ai"], G["doc_Ax"], np.array([1.0, 2.0, 3.0]))
+    assert np.array_equal(y, G["doc_matvec"])
+
+
+# ------------------------------------------------------------------ batch ---
+
+def test_batch_of_matrices_sharing_a_pattern(gpu, orc):
+    n = 1500
+    ei, ej = synth.spd_grid_pattern(n, seed=77)
+    mats = [synth.spd_grid_matrix(n, ei, ej, seed=100 + i) for i in range(4)]
+    m, n, Ap, Ai, _ = mats[0]
+    AX = np.stack([mm[4] for mm in mats])
+    B = np.random.default_rng(2).standard_normal((4, n, 2))
+    for kind in (gpu.CS3_LU, gpu.CS3_CHOLESKY):
+        with gpu.Factorization(m, n, Ap, Ai, kind=kind, batch=4) as F:
+            F.factor(AX, 1e-3 if kind == gpu.CS3_LU else 0.0)
+            X = F.solve(B)
+            q = F.ordering()["q"]
+            for i in range(4):
+                Lp, Li, Lx, Up, Ui, Ux = F.factors(b=i)
+                if kind == gpu.CS3_LU:
+                    oL = orc.csc_lu_f(n, n, Ap, Ai, AX[i], q, 1e-3)
+                    assert_factor_equal(n, (Lp, Li, Lx), oL[0:3], "batch L")
+                    assert_factor_equal(n, (Up, Ui, Ux), oL[3:6], "batch U")
+                else:
+                    assert_factor_equal(n, (Lp, Li, Lx), _oracle_chol(orc, n, Ap, Ai, AX[i], q), "batch chol L")
+                A = csc_to_scipy(m, n, Ap, Ai, AX[i])
+                assert np.abs(A @ X[i] - B[i]).max() <= 1e-11 * n
+
+
+# ------------------------------------------- full-size, size-independent ----
+
+def test_config3_full_size_properties(gpu):
+    """50k x 50k: residual, linearity of the solve, refactorisation idempotence,
+    run-to-run bitwise reproducibility (no float atomics on the path)."""
+    m, n, Ap, Ai, Ax = synth.grid_jacobian()
+    A = csc_to_scipy(m, n, Ap, Ai, Ax)
+    rng = np.random.default_rng(6)
+    b1, b2 = rng.standard_normal(n), rng.standard_normal(n)
+    with gpu.Factorization(m, n, Ap, Ai) as F:
+        F.factor(Ax, 1e-3)
+        x1, x2 = F.solve(b1), F.solve(b2)
+        x12 = F.solve(2.0 * b1 - 3.0 * b2)
+        L1 = F.factors()[2].copy()
+        F.factor(Ax, 1e-3)
+        assert np.array_equal(F.factors()[2], L1)                      # bitwise reproducible
+        assert np.array_equal(F.solve(b1), x1)
+        X = F.solve(np.stack([b1, b2], axis=1))
+    scale = abs(A).sum(axis=0).max()
+    for x, b in ((x1, b1), (x2, b2)):
+        assert np.abs(A @ x - b).max() <= 1e-13 * (scale * np.abs(x).max() + np.abs(b).max())
+    assert rel_err(x12, 2.0 * x1 - 3.0 * x2) <= 1e-12
+    assert rel_err(X[:, 0], x1) <= 1e-13 and rel_err(X[:, 1], x2) <= 1e-13

@@ -1,0 +1,121 @@
+"""Host-side mirror of the reference's matrix class for the factor/solve path.
+
+`CscMat` keeps the reference's constructor, attributes and accessors
+(/root/reference/src/CSparse3/csc.py:44-141, 459-538: m, n, indptr, indices,
+data, nzmax, get_nnz, shape, copy, todense, t) and adds the entry points the
+reference lacks at this snapshot: lu / chol / solve on the
+object, lusol / cholsol / lsolve / usolve as module functions.  Kernel names
+are star-imported from the backend module exactly as csc.py:34-41 does, so
+`from csparse3_amd.csc import *` exposes csc_lu_f, csc_lsolve_f, ... next to
+the class.
+"""
+import numpy as np
+
+from csparse3_amd import __config__
+
+if __config__.BACKEND != "hip":
+    raise ImportError("csparse3_amd has one numeric backend, 'hip' (got %r); there is no CPU fallback"
+                      % __config__.BACKEND)
+from csparse3_amd.csc_hip import *                       # noqa: F401,F403  (kernel names, reference style)
+from csparse3_amd import csc_hip as _k
+
+
+class CscMat:
+    """Matrix in compressed-column form (same fields as the reference's CscMat)."""
+
+    def __init__(self, m=0, n=0, nz_max=0, indptr=None, indices=None, data=None, zeros=False):
+        self.m, self.n = m, n
+        if indptr is None:
+            self.nzmax = max(nz_max, 1)
+            alloc = np.zeros if zeros else np.empty
+            self.indptr = alloc(n + 1, dtype=np.int32)
+            self.indices = alloc(nz_max, dtype=np.int32)
+            self.data = alloc(nz_max, dtype=np.float64)
+        else:
+            self.indptr, self.indices, self.data = indptr, indices, data
+            self.nzmax = len(self.data)
+        self._factorization = None
+
+    # ---- what the reference class already offers, kept for drop-in use
+    def get_nnz(self):
+        return self.indptr[self.n]                       # csc.py:480: nnz is indptr[n], not len(data)
+
+    @property
+    def shape(self):
+        return self.m, self.n
+
+    def copy(self):
+        return CscMat(self.m, self.n, indptr=self.indptr.copy(), indices=self.indices.copy(),
+                      data=self.data.copy())
+
+    def todense(self):
+        val = np.zeros((self.m, self.n), dtype=np.float64)
+        for j in range(self.n):
+            for p in range(self.indptr[j], self.indptr[j + 1]):
+                val[self.indices[p], j] = self.data[p]
+        return val
+
+    def __mul__(self, other):
+        """A * x for a vector or an [n, k] block, on the device (csc.py:372-415 semantics)."""
+        if isinstance(other, np.ndarray):
+            return _k.csc_mat_vec_ff(self.m, self.n, self.indptr, self.indices, self.data, other)
+        if isinstance(other, (int, float)):
+            C = self.copy()
+            C.data *= other
+            return C
+        raise Exception("Type not supported")
+
+    # ---- new: factor / solve
+    def _analysis(self, kind, order, q):
+        key = (kind, order, None if q is None else bytes(np.asarray(q, dtype=np.int32)))
+        f = self._factorization
+        if f is None or f[0] != key:
+            if f is not None:
+                f[1].close()
+            fac = _k.Factorization(self.m, self.n, self.indptr, self.indices, kind=kind, order=order, q=q)
+            self._factorization = f = (key, fac)
+        return f[1]
+
+    def lu(self, tol=0.0, order=_k.ORDER_AMD, q=None):
+        """Numeric LU on the device; the symbolic analysis is cached on the object, so calling
+        lu() again after changing .data is a refactorisation with the pattern reused."""
+        F = self._analysis(_k.CS3_LU, order, q)
+        F.factor(self.data, tol)
+        return F
+
+    def chol(self, order=_k.ORDER_AMD, q=None):
+        F = self._analysis(_k.CS3_CHOLESKY, order, q)
+        F.factor(self.data)
+        return F
+
+    def solve(self, b, tol=0.0):
+        """x = A \\ b by LU (factorises if needed)."""
+        return self.lu(tol).solve(b)
+
+
+def scipy_to_mat(scipy_mat):
+    """Alias SciPy's CSC arrays without copying (csc.py:541-553)."""
+    m, n = scipy_mat.shape
+    return CscMat(m, n, indptr=scipy_mat.indptr, indices=scipy_mat.indices, data=scipy_mat.data)
+
+
+def lusol(A, b, order=1, tol=0.0):
+    """x = A \\ b (cs_lusol)."""
+    return _k.csc_lusol_f(order, A.m, A.n, A.indptr, A.indices, A.data, b, tol)
+
+
+def cholsol(A, b, order=1):
+    """x = A \\ b for symmetric positive definite A (cs_cholsol)."""
+    return _k.csc_cholsol_f(order, A.m, A.n, A.indptr, A.indices, A.data, b)
+
+
+def lsolve(L, x):
+    """x = L \\ x in place, L a lower-triangular CscMat with the diagonal first in each column."""
+    _k.csc_lsolve_f(L.n, L.indptr, L.indices, L.data, x)
+    return x
+
+
+def usolve(U, x):
+    """x = U \\ x in place, U an upper-triangular CscMat with the diagonal last in each column."""
+    _k.csc_usolve_f(U.n, U.indptr, U.indices, U.data, x)
+    return x

@@ -75,6 +75,8 @@ def lib():
             f.argtypes = [vp, _f64p, I64]
         for f in (L.cs3_solve_dev, L.cs3_lsolve_dev, L.cs3_usolve_dev):
             f.argtypes = [vp, vp, I64, vp]
+        L.cs3_export_factor_dev.argtypes = [vp, vp, vp]
+        L.cs3_import_factor_dev.argtypes = [vp, vp, vp]
         L.cs3_get_factors.argtypes = [vp, I64, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p]
         L.cs3_amd.argtypes = [I64, I64, I64, _i32p, _i32p, _i32p]
         L.cs3_etree.argtypes = [I64, _i32p, _i32p, _i32p]
@@ -256,6 +258,14 @@ class Factorization:
 
     def usolve_dev(self, x_ptr, k=1, stream=0):
         _check(lib().cs3_usolve_dev(self._h, C.c_void_p(x_ptr), k, C.c_void_p(stream)))
+
+    def export_factor_dev(self, dst_ptr, stream=0):
+        """Copy the factor panels (info.factor_bytes per matrix) into an HBM buffer."""
+        _check(lib().cs3_export_factor_dev(self._h, C.c_void_p(dst_ptr), C.c_void_p(stream)))
+
+    def import_factor_dev(self, src_ptr, stream=0):
+        """Install factor panels produced by another handle with the same analysis."""
+        _check(lib().cs3_import_factor_dev(self._h, C.c_void_p(src_ptr), C.c_void_p(stream)))
 
     def factors(self, b=0, values=True):
         """-> (Lp, Li, Lx, Up, Ui, Ux) in CSparse form (U parts None for Cholesky)."""

@@ -466,6 +466,34 @@ int cs3_solve(cs3_handle h, double *X, int64_t k) { return solve_host(h, X, k, 0
 int cs3_lsolve(cs3_handle h, double *X, int64_t k) { return solve_host(h, X, k, 1); }
 int cs3_usolve(cs3_handle h, double *X, int64_t k) { return solve_host(h, X, k, 2); }
 
+int cs3_export_factor_dev(cs3_handle h, double *dst_dev, void *stream)
+{
+    int rc = guard(h); if (rc) return rc;
+    if (!h->factored) { set_error("cs3_export_factor_dev: nothing factorised"); return CS3_ERR_STATE; }
+    if (!dst_dev) { set_error("cs3_export_factor_dev: null buffer"); return CS3_ERR_ARG; }
+    const DeviceFactor &D = h->D;
+    if (D.vals_size > 0)
+        CS3_HIP(hipMemcpy2DAsync(dst_dev, (size_t) D.vals_size * sizeof(double), D.pool,
+                                 (size_t) D.pool_size * sizeof(double), (size_t) D.vals_size * sizeof(double),
+                                 (size_t) D.batch, hipMemcpyDeviceToDevice, (hipStream_t) stream));
+    return CS3_OK;
+}
+
+int cs3_import_factor_dev(cs3_handle h, const double *src_dev, void *stream)
+{
+    int rc = guard(h); if (rc) return rc;
+    if (!src_dev) { set_error("cs3_import_factor_dev: null buffer"); return CS3_ERR_ARG; }
+    if ((rc = ensure_device(h))) return rc;
+    const DeviceFactor &D = h->D;
+    if (D.vals_size > 0)
+        CS3_HIP(hipMemcpy2DAsync(D.pool, (size_t) D.pool_size * sizeof(double), src_dev,
+                                 (size_t) D.vals_size * sizeof(double), (size_t) D.vals_size * sizeof(double),
+                                 (size_t) D.batch, hipMemcpyDeviceToDevice, (hipStream_t) stream));
+    h->factored = true;
+    h->fail_col = -1;
+    return CS3_OK;
+}
+
 int cs3_debug_schedule(cs3_handle h, int32_t *sched, int32_t *front_r, int32_t *front_w)
 {
     int rc = guard(h); if (rc) return rc;

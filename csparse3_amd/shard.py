@@ -1,0 +1,182 @@
+"""Multi-GPU sharding of the two workloads of the path that shard.
+
+One process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on
+the GPU box, "gloo" in the CPU tests).  A single factorisation never spans
+GPUs; what shards is
+
+  * many right-hand sides of ONE matrix (BASELINE config 4): rank 0 factorises,
+    the factor panels are BROADCAST once (one collective of factor_bytes), every
+    rank solves its own slab of RHS columns, the solution slabs are GATHERED;
+  * many independent matrices (BASELINE config 5): every rank factorises and
+    solves its own slice of the batch -- no data-path collective at all, only
+    the final gather of the solutions.
+
+The numeric work goes through a `backend` object so that the partitioning and
+the collectives can be exercised on CPU with gloo (tests/test_shard.py uses the
+oracle as the backend there); `HipBackend` is the real one.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total, world, rank):
+    """Contiguous, balanced [lo, hi) of `total` items for `rank` of `world`."""
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+class HipBackend:
+    """The MI355X backend: a csc_hip.Factorization plus torch tensors for HBM buffers."""
+
+    def __init__(self, m, n, Ap, Ai, kind=0, batch=1, device=None):
+        from csparse3_amd import csc_hip
+        self.hip = csc_hip
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.F = csc_hip.Factorization(m, n, Ap, Ai, kind=kind, batch=batch)
+        self.n, self.batch = n, batch
+
+    def stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def factor(self, Ax, tol=0.0):
+        ax = torch.as_tensor(np.ascontiguousarray(Ax), dtype=torch.float64).to(self.device)
+        self.F.factor_dev(ax.data_ptr(), tol, self.stream())
+        self.F.factor_status(self.stream())
+
+    def factor_size(self):
+        return int(self.F.info.factor_bytes // 8) * self.batch
+
+    def export_factor(self):
+        """Factor panels as one flat device tensor (what gets broadcast)."""
+        buf = torch.empty(self.factor_size(), dtype=torch.float64, device=self.device)
+        self.F.export_factor_dev(buf.data_ptr(), self.stream())
+        return buf
+
+    def import_factor(self, buf):
+        self.F.import_factor_dev(buf.data_ptr(), self.stream())
+
+    def empty_factor(self):
+        return torch.empty(self.factor_size(), dtype=torch.float64, device=self.device)
+
+    def solve(self, B):
+        """B: torch tensor [n, k] (or [batch, n, k]) on the device; solved in place, returned."""
+        k = B.shape[-1]
+        self.F.solve_dev(B.data_ptr(), k, self.stream())
+        return B
+
+    def to_device(self, a):
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).to(self.device)
+
+
+def solve_many_rhs(backend, Ax, B, tol=0.0, group=None, root=0):
+    """Config 4: A X = B with B [n, k] known on `root`; returns X [n, k] on root, None elsewhere.
+
+    Collectives: one broadcast of the factor panels, one gather of the solution slabs.
+    """
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    n, k = B.shape if rank == root else (None, None)
+    meta = torch.tensor([n or 0, k or 0], dtype=torch.int64)
+    if world > 1:
+        meta = meta.to(_comm_device(backend))
+        dist.broadcast(meta, src=root, group=group)
+    n, k = int(meta[0]), int(meta[1])
+    # ---- factor once, broadcast the panels
+    if rank == root:
+        backend.factor(Ax, tol)
+        fac = backend.export_factor()
+    else:
+        fac = backend.empty_factor()
+    if world > 1:
+        dist.broadcast(fac, src=root, group=group)
+        if rank != root:
+            backend.import_factor(fac)
+    # ---- scatter the RHS columns as contiguous slabs [n, k_r]
+    lo, hi = shard_range(k, world, rank)
+    if world > 1:
+        if rank == root:
+            Bd = backend.to_device(B)
+            slabs = [Bd[:, slice(*shard_range(k, world, r))].contiguous() for r in range(world)]
+        else:
+            slabs = None
+        mine = torch.empty((n, hi - lo), dtype=torch.float64, device=fac.device)
+        _scatter_uneven(mine, slabs, root, group)
+    else:
+        mine = backend.to_device(B).contiguous()
+    if hi > lo:
+        backend.solve(mine)
+    # ---- gather the solution slabs
+    if world == 1:
+        return mine
+    out = _gather_uneven(mine, [(n, shard_range(k, world, r)[1] - shard_range(k, world, r)[0])
+                                for r in range(world)], root, group)
+    if rank != root:
+        return None
+    return torch.cat(out, dim=1)
+
+
+def solve_many_matrices(make_backend, AX, B, tol=0.0, group=None, root=0):
+    """Config 5: AX [nmat, nnz] values of matrices sharing one pattern, B [nmat, n, k] right-hand
+    sides, both known on every rank (synthetic inputs are generated from seeds); each rank
+    factorises and solves its slice.  Returns X [nmat, n, k] on root, None elsewhere.
+    `make_backend(batch)` builds a backend for `batch` matrices."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    nmat = AX.shape[0]
+    lo, hi = shard_range(nmat, world, rank)
+    X = None
+    be = None
+    if hi > lo:
+        be = make_backend(hi - lo)
+        be.factor(AX[lo:hi], tol)
+        X = be.solve(be.to_device(B[lo:hi]).contiguous())
+    if world == 1:
+        return X
+    shapes = [(shard_range(nmat, world, r)[1] - shard_range(nmat, world, r)[0],) + tuple(B.shape[1:])
+              for r in range(world)]
+    dev = X.device if X is not None else _comm_device(be)
+    if X is None:
+        X = torch.empty((0,) + tuple(B.shape[1:]), dtype=torch.float64, device=dev)
+    out = _gather_uneven(X, shapes, root, group)
+    return torch.cat(out, dim=0) if rank == root else None
+
+
+def _comm_device(backend):
+    dev = getattr(backend, "device", None)
+    return dev if dev is not None else torch.device("cpu")
+
+
+def _scatter_uneven(recv, slabs, root, group):
+    """Point-to-point fan-out from root (slabs differ in width, so no scatter collective)."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if rank == root:
+        reqs = []
+        for r in range(world):
+            if r == root:
+                recv.copy_(slabs[r])
+            elif slabs[r].numel() > 0:
+                reqs.append(dist.isend(slabs[r], dst=r, group=group))
+        for q in reqs:
+            q.wait()
+    elif recv.numel() > 0:
+        dist.recv(recv, src=root, group=group)
+
+
+def _gather_uneven(send, shapes, root, group):
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if rank == root:
+        out, reqs = [], []
+        for r in range(world):
+            if r == root:
+                out.append(send)
+                continue
+            t = torch.empty(shapes[r], dtype=send.dtype, device=send.device)
+            out.append(t)
+            if t.numel() > 0:
+                reqs.append(dist.irecv(t, src=r, group=group))
+        for q in reqs:
+            q.wait()
+        return out
+    if send.numel() > 0:
+        dist.send(send, dst=root, group=group)
+    return None

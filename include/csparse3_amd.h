@@ -130,6 +130,15 @@ int cs3_usolve_dev(cs3_handle h, double *X_dev, int64_t k, void *stream);
 int cs3_get_factors(cs3_handle h, int64_t b, int32_t *Lp, int32_t *Li, double *Lx,
                     int32_t *Up, int32_t *Ui, double *Ux);
 
+/* ---- moving a factorisation between GPUs (BASELINE config 4) -----------
+ * The numeric state of a handle is its factor panels: cs3_info.factor_bytes
+ * per matrix, batch matrices back to back.  Export copies them into a caller
+ * buffer in HBM (which RCCL then broadcasts); import installs such a buffer in
+ * a handle that analysed the SAME pattern with the SAME ordering, after which
+ * it solves as if it had factorised itself. */
+int cs3_export_factor_dev(cs3_handle h, double *dst_dev, void *stream);
+int cs3_import_factor_dev(cs3_handle h, const double *src_dev, void *stream);
+
 /* ---- diagnostics --------------------------------------------------------
  * With CS3_PROFILE=1 in the environment every LDS-resident front records six
  * shader-clock stamps (descriptor read, zeroed, assembled, eliminated, staged,

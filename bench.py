@@ -164,6 +164,13 @@ def main():
         bytes_solve = (12 * nnz_l + 4 * (n + 1) + 16 * n * args.rhs) + \
                       (12 * nnz_u + 4 * (n + 1) + 16 * n * args.rhs) + 2 * 8 * n * args.rhs
         achieved = bytes_factor / (t_factor_ms * 1e-3) / 1e9
+        traffic = None                               # PMC bytes per factorisation, from the committed profile
+        try:
+            import glob
+            tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
+            traffic = json.load(open(tf))["factor"]["hbm_bytes_corrected"] if args.n == 50000 else None
+        except Exception:
+            traffic = None
         out = {
             "metric": "numeric-LU + lsolve/usolve nnz/s on 50k power-grid Jacobian",
             "value": world * units * args.steps / elapsed,
@@ -184,11 +191,12 @@ def main():
                        "max_front": int(info.max_front), "ordering": "amd(A+A')",
                        "parallelism": "independent matrices per rank, no collective"},
             "roofline": {"bound": "hbm",
-                         "kernel": "numeric factorisation (k_assemble + k_front_* level launches, one hipGraph)",
+                         "kernel": "numeric factorisation = one hipGraph of k_front_lds / k_big_gather / k_big_step "
+                                   "launches (one per tree level and size class, one per 32 pivots of a big front)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "frac_of_measured_peak": achieved / HBM_MEASURED_GBS,
-                         "traffic": None,
+                         "traffic": traffic,
                          "algorithmic_bytes": bytes_factor,
                          "avg_launch_ms": t_factor_ms,
                          "note": "dependency-depth bound: %d tree levels per factorisation" % int(info.nlevels)},

@@ -39,6 +39,13 @@ __device__ __forceinline__ double load_if(const double *__restrict__ p, long lon
     return ok ? v : 0.0;
 }
 
+__device__ __forceinline__ double bcast_lane(double x, int k)     // k wave-uniform
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), k);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), k);
+    return __hiloint2double(hi, lo);
+}
+
 constexpr int ASM_DUMMY_T = 0x3fffffff;
 constexpr int ASM_LONG_T = 0x40000000;
 constexpr int GATHER_UNROLL = 4;
@@ -183,6 +190,7 @@ k_front_lds(const FrontDesc *__restrict__ fdesc, int first,
         __syncthreads();
         const double piv = urow[k];
         const double dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
+        const double rdg = 1.0 / dg;               // one divide per pivot: multipliers are x * (1 / pivot)
         if (ty == tyk) {                           // 2. column k / pivot -> lcol
 #pragma unroll
             for (int b = 0; b < RJ; ++b)
@@ -191,7 +199,7 @@ k_front_lds(const FrontDesc *__restrict__ fdesc, int first,
                     for (int a = 0; a < RI; ++a) {
                         const int i = tx + TX * a;
                         if (i > k && i < r) {
-                            R[a][b] /= dg;
+                            R[a][b] *= rdg;
                             lcol[i] = R[a][b];
                             if (KIND == CS3_LU && !(fabs(R[a][b]) <= inv_tol)) flag_column(status, d.c0 + k);
                         }
@@ -268,6 +276,49 @@ k_big_gather(const FrontDesc *__restrict__ fdesc, int first,
                  asm_src, asm_tgt, long_src,
                  [&](int q) -> const double * { return (q >= 0) ? pool + q : ax + ~q; },
                  [&](int t, double v) { pool[t] = v; });
+}
+
+// Unblocked LU / Cholesky of a bw x bw block (bw <= 32) held in LDS, by ONE wave and without
+// barriers: lane i keeps row i in 32 registers; for pivot k the pivot row is read lane-to-scalar
+// (v_readlane), so a step is (bw - k) scalar-operand FMAs plus one divide.  k is unrolled so that
+// every register index is static.
+template <int KIND>
+__device__ __forceinline__ void factor_block32(double (*D)[BIG_NB + 1], int bw)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = lane < bw ? lane : 0;
+    double d[BIG_NB];
+#pragma unroll
+    for (int j = 0; j < BIG_NB; ++j) d[j] = D[row][j];
+#pragma unroll
+    for (int k = 0; k < BIG_NB; ++k) {
+        if (k < bw) {                                   // wave-uniform
+            const double piv = bcast_lane(d[k], k);
+            if (KIND == CS3_LU) {
+                const double l = d[k] / piv;
+                if (lane > k) d[k] = l;
+#pragma unroll
+                for (int j = k + 1; j < BIG_NB; ++j) {
+                    const double u = bcast_lane(d[j], k);
+                    if (lane > k) d[j] -= l * u;
+                }
+            } else {
+                const double dg = sqrt(piv);
+                const double l = d[k] / dg;
+                if (lane > k) d[k] = l;
+                if (lane == k) d[k] = (piv > 0.0) ? dg : -1.0;
+#pragma unroll
+                for (int j = k + 1; j < BIG_NB; ++j) {
+                    const double lj = bcast_lane(d[k], j);      // L(j, k), already scaled (j > k)
+                    if (lane >= j) d[j] -= l * lj;
+                }
+            }
+        }
+    }
+    if (lane < bw) {
+#pragma unroll
+        for (int j = 0; j < BIG_NB; ++j) D[lane][j] = d[j];
+    }
 }
 
 // Blocked right-looking LU / Cholesky with ONE launch per block step.
@@ -424,29 +475,8 @@ k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__res
             for (int u = 0; u < 2; ++u) T[ty + 16 * v][tx + 16 * u] = acc[u][v];
     }
     __syncthreads();
-    for (int k = 0; k < bw; ++k) {
-        const double piv = D[k][k];
-        if (KIND == CS3_LU) {
-            if (tid > k && tid < bw) D[tid][k] /= piv;
-            __syncthreads();
-            const int i = k + 1 + di;
-            if (i < bw) {
-                const double l = D[i][k];
-                for (int j = k + 1 + dj; j < bw; j += 8) D[i][j] -= l * D[k][j];
-            }
-        } else {
-            const double dg = sqrt(piv);
-            if (tid > k && tid < bw) D[tid][k] /= dg;
-            __syncthreads();
-            if (tid == 0) D[k][k] = (piv > 0.0) ? dg : -1.0;
-            const int i = k + 1 + di;
-            if (i < bw) {
-                const double l = D[i][k];
-                for (int j = k + 1 + dj; j < bw; j += 8) if (i >= j) D[i][j] -= l * D[j][k];
-            }
-        }
-        __syncthreads();
-    }
+    if (tid < 64) factor_block32<KIND>(D, bw);      // wave 0: lane = row, the row lives in registers
+    __syncthreads();
     if (bi == 0 && bj == 0) {                       // park the factored block, check its pivots
         double *db = dbuf + (long long) (kb / BIG_NB) * (BIG_NB * BIG_NB);
         for (int e = tid; e < bw * bw; e += 256) {
@@ -511,12 +541,6 @@ k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__res
 // waits on memory by itself.
 constexpr int SOLVE_PF = 8;
 
-__device__ __forceinline__ double bcast_lane(double x, int k)     // k wave-uniform
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(x), k);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), k);
-    return __hiloint2double(hi, lo);
-}
 
 // One wave per front (r <= 128, w <= 64): lane l owns rows l and l + 64.
 template <int KIND>

@@ -252,3 +252,97 @@ def test_config3_full_size_properties(gpu):
         assert np.abs(A @ x - b).max() <= 1e-13 * (scale * np.abs(x).max() + np.abs(b).max())
     assert rel_err(x12, 2.0 * x1 - 3.0 * x2) <= 1e-12
     assert rel_err(X[:, 0], x1) <= 1e-13 and rel_err(X[:, 1], x2) <= 1e-13
+
+
+# ------------------------------------------------------------- edge cases ----
+
+def _arrow_with_dense_row(n=400, seed=0):
+    """One node coupled to 3/4 of the others: exercises AMD's dense-row deferral (degree > 10 sqrt n)."""
+    rng = np.random.default_rng(seed)
+    hub = 17
+    others = np.setdiff1d(np.arange(n), [hub])
+    nb = rng.choice(others, size=3 * n // 4, replace=False)
+    ei = np.concatenate([np.full(len(nb), hub), np.arange(n - 1)])
+    ej = np.concatenate([nb, np.arange(1, n)])
+    ei, ej = synth._unique_edges(n, ei, ej)
+    return synth._graph_to_matrix(n, ei, ej, rng)
+
+
+def _block_diagonal(seed=0):
+    """Three disconnected islands plus isolated nodes: a forest with several roots."""
+    import scipy.sparse as sp
+    blocks = [sp.csc_matrix((b[4], b[3], b[2]), shape=(b[1], b[1]))
+              for b in (synth.grid_jacobian(n=150, seed=seed), synth.jacobian_like(nbus=30, nedges=40, n_pv=5, seed=seed + 1),
+                        synth.grid_jacobian(n=60, seed=seed + 2))]
+    blocks.append(sp.diags(np.arange(2.0, 7.0)).tocsc())
+    A = sp.block_diag(blocks, format="csc"); A.sort_indices()
+    n = A.shape[0]
+    return n, n, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy()
+
+
+EDGE = {
+    "n1": (1, 1, np.array([0, 1], dtype=np.int32), np.array([0], dtype=np.int32), np.array([4.0])),
+    "diagonal": (6, 6, np.arange(7, dtype=np.int32), np.arange(6, dtype=np.int32), np.arange(1.0, 7.0)),
+    "dense_row": _arrow_with_dense_row(),
+    "islands": _block_diagonal(),
+}
+
+
+@pytest.mark.parametrize("name", list(EDGE))
+def test_edge_structures(gpu, orc, name):
+    m, n, Ap, Ai, Ax = EDGE[name]
+    assert np.array_equal(gpu.csc_amd_f(1, m, n, Ap, Ai), orc.csc_amd_f(1, m, n, Ap, Ai))
+    Lp, Li, Lx, Up, Ui, Ux, pinv, q = gpu.csc_lu_f(m, n, Ap, Ai, Ax, tol=1e-3)
+    oL = orc.csc_lu_f(n, n, Ap, Ai, Ax, q, 1e-3)
+    assert np.array_equal(pinv, oL[6])
+    assert_factor_equal(n, (Lp, Li, Lx), oL[0:3], name + " L")
+    assert_factor_equal(n, (Up, Ui, Ux), oL[3:6], name + " U")
+    b = np.arange(1.0, n + 1.0)
+    x = gpu.csc_lusol_f(1, m, n, Ap, Ai, Ax, b, tol=1e-3)
+    assert rel_err(x, orc.csc_lusol_f(1, n, Ap, Ai, Ax, b, 1e-3)) <= RTOL
+
+
+def test_unsorted_rows_and_slack_storage(gpu, orc):
+    """CscMat may hold unsorted columns (csc_numba.py:334-335) and arrays longer than nnz (csc.py:138)."""
+    m, n, Ap, Ai, Ax = CASES["grid2k"]
+    rng = np.random.default_rng(5)
+    Ai2, Ax2 = Ai.copy(), Ax.copy()
+    for j in range(n):
+        p = rng.permutation(Ap[j + 1] - Ap[j]) + Ap[j]
+        Ai2[Ap[j]:Ap[j + 1]] = Ai[p]; Ax2[Ap[j]:Ap[j + 1]] = Ax[p]
+    Ai2 = np.concatenate([Ai2, np.full(50, -7, dtype=np.int32)])       # garbage beyond Ap[n] must be ignored
+    Ax2 = np.concatenate([Ax2, np.full(50, np.nan)])
+    b = rng.standard_normal(n)
+    x = gpu.csc_lusol_f(1, m, n, Ap, Ai2, Ax2, b, tol=1e-3)
+    assert rel_err(x, orc.csc_lusol_f(1, n, Ap, Ai, Ax, b, 1e-3)) <= RTOL
+
+
+def test_entry_with_more_than_64_contributions(gpu, orc):
+    """A hub whose 90 leaf neighbours each update its diagonal: the gather's long-run path."""
+    n = 120
+    rng = np.random.default_rng(2)
+    hub = n - 1
+    ei = np.concatenate([np.arange(90), np.arange(90, n - 2)])
+    ej = np.concatenate([np.full(90, hub), np.arange(91, n - 1)])
+    m, n, Ap, Ai, Ax = synth._graph_to_matrix(n, *synth._unique_edges(n, ei, ej), rng)
+    q = np.arange(n, dtype=np.int32)                                    # natural order keeps the hub last
+    with gpu.Factorization(m, n, Ap, Ai, q=q) as F:
+        F.factor(Ax, 1e-3)
+        Lp, Li, Lx, Up, Ui, Ux = F.factors()
+        qq = F.ordering()["q"]
+        x = F.solve(np.ones(n))
+    oL = orc.csc_lu_f(n, n, Ap, Ai, Ax, qq, 1e-3)
+    assert_factor_equal(n, (Up, Ui, Ux), oL[3:6], "hub U")
+    assert np.abs(csc_to_scipy(m, n, Ap, Ai, Ax) @ x - 1.0).max() < 1e-12
+
+
+def test_call_order_and_argument_errors(gpu):
+    m, n, Ap, Ai, Ax = CASES["toy10"]
+    with gpu.Factorization(m, n, Ap, Ai) as F:
+        with pytest.raises(gpu.Cs3Error):
+            F.solve(np.ones(n))                              # solve before factor
+        F.factor(Ax)
+        with pytest.raises(AssertionError):
+            F.solve(np.ones(n + 1))                          # wrong length
+        x = F.solve(np.ones((n, 3)))
+        assert x.shape == (n, 3)

@@ -115,6 +115,45 @@ __device__ __forceinline__ void gather_front(long long asm_begin, int nchunks, i
     }
 }
 
+// The same gather for NV values per source (NV right-hand sides, contiguous in memory):
+// fetch(s) returns the address of value 0 of source s, nlive of the NV are real.
+template <int NV, class Fetch, class Store>
+__device__ __forceinline__ void gather_front_vec(long long asm_begin, int nchunks, const int *__restrict__ asm_src,
+                                                 const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
+                                                 int nlive, Fetch fetch, Store store)
+{
+    const int lane = threadIdx.x & 63;
+    for (int c = 0; c < nchunks; ++c) {
+        const long long idx = asm_begin + (long long) c * 64 + lane;
+        const int t = asm_tgt[idx], s = asm_src[idx];
+        const int s_next = __shfl_down(s, 1);
+        const bool is_long = (t & ASM_LONG_T) != 0 && t != ASM_DUMMY_T;
+        const bool plain = !is_long && t != ASM_DUMMY_T;
+        const double *src = fetch(plain ? s : 0);
+        double v[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const double x = src[q < nlive ? q : 0];
+            v[q] = (plain && q < nlive) ? x : 0.0;
+        }
+        if (is_long) {
+            for (int k = 0; k < s_next; ++k) {
+                const double *p = fetch(long_src[s + k]);
+#pragma unroll
+                for (int q = 0; q < NV; ++q) if (q < nlive) v[q] += p[q];
+            }
+        }
+        const int tt = t & ~ASM_LONG_T;
+        bool is_last = false;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) is_last = run_totals(tt, v[q]);
+        if (is_last && tt != ASM_DUMMY_T) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) store(tt, q, v[q]);
+        }
+    }
+}
+
 __device__ __forceinline__ void flag_column(int *status, int col)
 {
     atomicMin(status, col);
@@ -542,34 +581,38 @@ k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__res
 constexpr int SOLVE_PF = 8;
 
 
-// One wave per front (r <= 128, w <= 64): lane l owns rows l and l + 64.
-template <int KIND>
+// One wave per front (r <= 128, w <= 64): lane l owns rows l and l + 64, for KT
+// right-hand sides at once (blockIdx.z = tile of KT columns of X): the panel is
+// read once per tile.
+template <int KIND, int KT>
 __global__ void __launch_bounds__(256)
 k_fwd_wave(const SolveDesc *__restrict__ sd, int first, int count,
            const int *__restrict__ fsrc, const int *__restrict__ ftgt, const int *__restrict__ flong,
            const double *__restrict__ pool_all, double *__restrict__ cv_all, double *__restrict__ X_all,
            int nrhs, long long pool_stride, long long cv_stride, long long x_stride)
 {
-    __shared__ double vs[4][132];
+    __shared__ double vs[4][KT][132];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int task = blockIdx.x * 4 + wv;
     if (task >= count) return;
     const SolveDesc d = sd[first + task];
-    const int rhs = blockIdx.z;
+    const int t0 = blockIdx.z * KT, nlive = min(KT, nrhs - t0);
     const double *pool = pool_all + (long long) blockIdx.y * pool_stride;
     double *cv = cv_all + (long long) blockIdx.y * cv_stride;
     double *X = X_all + (long long) blockIdx.y * x_stride;
     const int r = d.r, w = d.w;
-    double *v = vs[wv];
-    v[lane] = 0.0; v[lane + 64] = 0.0;
+#pragma unroll
+    for (int q = 0; q < KT; ++q) { vs[wv][q][lane] = 0.0; vs[wv][q][lane + 64] = 0.0; }
     __builtin_amdgcn_wave_barrier();
-    gather_front(d.fasm_begin, d.fasm_count >> 6, 0, GATHER_UNROLL, fsrc, ftgt, flong,
-                 [&](int q) -> const double * {
-                     return (q >= 0) ? cv + (long long) q * nrhs + rhs : X + (long long) (~q) * nrhs + rhs;
-                 },
-                 [&](int t, double val) { v[t] = val; });
+    gather_front_vec<KT>(d.fasm_begin, d.fasm_count >> 6, fsrc, ftgt, flong, nlive,
+                         [&](int q) -> const double * {
+                             return (q >= 0) ? cv + (long long) q * nrhs + t0 : X + (long long) (~q) * nrhs + t0;
+                         },
+                         [&](int t, int q, double val) { vs[wv][q][t] = val; });
     __builtin_amdgcn_wave_barrier();
-    double v0 = v[lane], v1 = v[lane + 64];
+    double v0[KT], v1[KT];
+#pragma unroll
+    for (int q = 0; q < KT; ++q) { v0[q] = vs[wv][q][lane]; v1[q] = vs[wv][q][lane + 64]; }
     const double *L = pool + d.lpan;
     for (int k0 = 0; k0 < w; k0 += SOLVE_PF) {
         double l0[SOLVE_PF], l1[SOLVE_PF];
@@ -583,21 +626,29 @@ k_fwd_wave(const SolveDesc *__restrict__ sd, int first, int count,
         for (int j = 0; j < SOLVE_PF; ++j) {
             const int k = k0 + j;
             if (k < w) {
-                if (KIND == CS3_CHOLESKY && lane == k) v0 /= l0[j];
-                const double xk = bcast_lane(v0, k);
-                if (lane > k) v0 -= l0[j] * xk;
-                v1 -= l1[j] * xk;
+#pragma unroll
+                for (int q = 0; q < KT; ++q) {
+                    if (KIND == CS3_CHOLESKY && lane == k) v0[q] /= l0[j];
+                    const double xk = bcast_lane(v0[q], k);
+                    if (lane > k) v0[q] -= l0[j] * xk;
+                    v1[q] -= l1[j] * xk;
+                }
             }
         }
     }
-    if (lane < w) X[(long long) (d.c0 + lane) * nrhs + rhs] = v0;
-    if (d.parent >= 0) {
-        if (lane >= w && lane < r) cv[(d.cv + lane - w) * nrhs + rhs] = v0;
-        if (lane + 64 < r) cv[(d.cv + lane + 64 - w) * nrhs + rhs] = v1;
+#pragma unroll
+    for (int q = 0; q < KT; ++q) {
+        if (q < nlive) {
+            if (lane < w) X[(long long) (d.c0 + lane) * nrhs + t0 + q] = v0[q];
+            if (d.parent >= 0) {
+                if (lane >= w && lane < r) cv[(d.cv + lane - w) * nrhs + t0 + q] = v0[q];
+                if (lane + 64 < r) cv[(d.cv + lane + 64 - w) * nrhs + t0 + q] = v1[q];
+            }
+        }
     }
 }
 
-template <int KIND>
+template <int KIND, int KT>
 __global__ void __launch_bounds__(256)
 k_bwd_wave(const SolveDesc *__restrict__ sd, int first, int count, const int *__restrict__ st_idx,
            const double *__restrict__ pool_all, double *__restrict__ X_all,
@@ -607,7 +658,7 @@ k_bwd_wave(const SolveDesc *__restrict__ sd, int first, int count, const int *__
     const int task = blockIdx.x * 4 + wv;
     if (task >= count) return;
     const SolveDesc d = sd[first + task];
-    const int rhs = blockIdx.z;
+    const int t0 = blockIdx.z * KT, nlive = min(KT, nrhs - t0);
     const double *pool = pool_all + (long long) blockIdx.y * pool_stride;
     double *X = X_all + (long long) blockIdx.y * x_stride;
     const int r = d.r, w = d.w;
@@ -615,8 +666,12 @@ k_bwd_wave(const SolveDesc *__restrict__ sd, int first, int count, const int *__
     const int i1 = lane + 64;
     const int row0 = (lane < w) ? d.c0 + lane : st[lane < r ? lane : 0];
     const int row1 = st[i1 < r ? i1 : 0];
-    double v0 = load_if(X, (long long) row0 * nrhs + rhs, lane < r);
-    const double v1 = load_if(X, (long long) row1 * nrhs + rhs, i1 < r);
+    double v0[KT], v1[KT];
+#pragma unroll
+    for (int q = 0; q < KT; ++q) {
+        v0[q] = load_if(X, (long long) row0 * nrhs + t0 + q, lane < r && q < nlive);
+        v1[q] = load_if(X, (long long) row1 * nrhs + t0 + q, i1 < r && q < nlive);
+    }
     const double *L = pool + d.lpan;
     const double *U = pool + d.upan;
     // pivot row `lane` minus U(lane, k) x_k over the ancestors k = w .. r-1
@@ -633,8 +688,11 @@ k_bwd_wave(const SolveDesc *__restrict__ sd, int first, int count, const int *__
         for (int j = 0; j < SOLVE_PF; ++j) {
             const int k = k0 + j;
             if (k < r) {
-                const double xk = (k < 64) ? bcast_lane(v0, k) : bcast_lane(v1, k - 64);
-                v0 -= u[j] * xk;
+#pragma unroll
+                for (int q = 0; q < KT; ++q) {
+                    const double xk = (k < 64) ? bcast_lane(v0[q], k) : bcast_lane(v1[q], k - 64);
+                    v0[q] -= u[j] * xk;
+                }
             }
         }
     }
@@ -652,13 +710,18 @@ k_bwd_wave(const SolveDesc *__restrict__ sd, int first, int count, const int *__
         for (int j = 0; j < SOLVE_PF; ++j) {
             const int k = k0 - j;
             if (k >= 0) {
-                if (lane == k) v0 /= u[j];
-                const double xk = bcast_lane(v0, k);
-                if (lane < k) v0 -= u[j] * xk;
+#pragma unroll
+                for (int q = 0; q < KT; ++q) {
+                    if (lane == k) v0[q] /= u[j];
+                    const double xk = bcast_lane(v0[q], k);
+                    if (lane < k) v0[q] -= u[j] * xk;
+                }
             }
         }
     }
-    if (lane < w) X[(long long) (d.c0 + lane) * nrhs + rhs] = v0;
+#pragma unroll
+    for (int q = 0; q < KT; ++q)
+        if (lane < w && q < nlive) X[(long long) (d.c0 + lane) * nrhs + t0 + q] = v0[q];
 }
 
 // One workgroup per front (any size): the front vector lives in LDS, the pivot
@@ -976,13 +1039,24 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
     const long long xs = D.n * (long long) nrhs;
     const long long cvs = D.cv_size * (long long) nrhs;
     if (g.cls == 0) {
-        dim3 grid((unsigned) ((g.count + 3) / 4), (unsigned) D.batch, (unsigned) nrhs);
-        if (forward)
-            hipLaunchKernelGGL((k_fwd_wave<KIND>), grid, dim3(256), 0, st, D.sdesc, g.first, g.count, D.fasm_src,
-                               D.fasm_tgt, D.flong_src, D.pool, D.cv, X, nrhs, D.pool_size, cvs, xs);
-        else
-            hipLaunchKernelGGL((k_bwd_wave<KIND>), grid, dim3(256), 0, st, D.sdesc, g.first, g.count, D.st_idx,
-                               D.pool, X, nrhs, D.pool_size, xs);
+        if (nrhs == 1) {
+            dim3 grid((unsigned) ((g.count + 3) / 4), (unsigned) D.batch, 1);
+            if (forward)
+                hipLaunchKernelGGL((k_fwd_wave<KIND, 1>), grid, dim3(256), 0, st, D.sdesc, g.first, g.count, D.fasm_src,
+                                   D.fasm_tgt, D.flong_src, D.pool, D.cv, X, nrhs, D.pool_size, cvs, xs);
+            else
+                hipLaunchKernelGGL((k_bwd_wave<KIND, 1>), grid, dim3(256), 0, st, D.sdesc, g.first, g.count, D.st_idx,
+                                   D.pool, X, nrhs, D.pool_size, xs);
+        } else {
+            constexpr int KT = 8;                   // right-hand sides per wave: the panel is read once per tile
+            dim3 grid((unsigned) ((g.count + 3) / 4), (unsigned) D.batch, (unsigned) ((nrhs + KT - 1) / KT));
+            if (forward)
+                hipLaunchKernelGGL((k_fwd_wave<KIND, KT>), grid, dim3(256), 0, st, D.sdesc, g.first, g.count, D.fasm_src,
+                                   D.fasm_tgt, D.flong_src, D.pool, D.cv, X, nrhs, D.pool_size, cvs, xs);
+            else
+                hipLaunchKernelGGL((k_bwd_wave<KIND, KT>), grid, dim3(256), 0, st, D.sdesc, g.first, g.count, D.st_idx,
+                                   D.pool, X, nrhs, D.pool_size, xs);
+        }
     } else {
         dim3 grid((unsigned) g.count, (unsigned) D.batch, (unsigned) nrhs);
         const size_t lds = (size_t) (g.max_r + 1 + SOLVE_BW) * sizeof(double);

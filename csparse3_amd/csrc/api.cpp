@@ -37,6 +37,7 @@ struct cs3_handle_s {
     bool on_device = false, factored = false;
     bool use_graph = true;
     hipStream_t cap_stream = nullptr;
+    ForkJoin fj;
     hipGraphExec_t factor_graph = nullptr;
     double factor_graph_inv_tol = 0.0;
     std::map<int, hipGraphExec_t> solve_graphs;   // keyed by nrhs
@@ -141,6 +142,7 @@ int ensure_device(cs3_handle h)
         }
     }
     CS3_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+    CS3_HIP(h->fj.init());
     const char *ng = std::getenv("CS3_NO_GRAPH");
     h->use_graph = !(ng && ng[0] == '1');
     h->on_device = true;
@@ -192,14 +194,14 @@ int run_factor(cs3_handle h, const double *ax_dev, double tol, hipStream_t st)
         }
         if (!h->factor_graph) {
             int rc = capture(h, &h->factor_graph, [&](hipStream_t cs) {
-                return launch_factor_levels(D, h->S.groups, inv_tol, cs);
+                return launch_factor_levels(D, h->S.groups, inv_tol, cs, h->fj);
             });
             if (rc) return rc;
             h->factor_graph_inv_tol = inv_tol;
         }
         CS3_HIP(hipGraphLaunch(h->factor_graph, st));
     } else {
-        CS3_HIP(launch_factor_levels(D, h->S.groups, inv_tol, st));
+        CS3_HIP(launch_factor_levels(D, h->S.groups, inv_tol, st, h->fj));
     }
     h->factored = true;
     return CS3_OK;
@@ -238,21 +240,21 @@ int run_solve(cs3_handle h, double *x_dev, long long k, int mode, hipStream_t st
             if (it == h->solve_graphs.end()) {
                 hipGraphExec_t exec = nullptr;
                 rc = capture(h, &exec, [&](hipStream_t cs) {
-                    hipError_t e = launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, true, cs);
+                    hipError_t e = launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, true, cs, h->fj);
                     if (e != hipSuccess) return e;
-                    return launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, false, cs);
+                    return launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, false, cs, h->fj);
                 });
                 if (rc) return rc;
                 it = h->solve_graphs.emplace(nrhs, exec).first;
             }
             CS3_HIP(hipGraphLaunch(it->second, st));
         } else {
-            CS3_HIP(launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, true, st));
-            CS3_HIP(launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, false, st));
+            CS3_HIP(launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, true, st, h->fj));
+            CS3_HIP(launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, false, st, h->fj));
         }
         CS3_HIP(launch_permute(D, D.xp, x_dev, nrhs, true, st));
     } else {
-        CS3_HIP(launch_solve_levels(D, h->S.sgroups, x_dev, nrhs, mode == 1, st));
+        CS3_HIP(launch_solve_levels(D, h->S.sgroups, x_dev, nrhs, mode == 1, st, h->fj));
     }
     return CS3_OK;
 }
@@ -347,6 +349,7 @@ int cs3_free(cs3_handle h)
         if (h->factor_graph) (void) hipGraphExecDestroy(h->factor_graph);
         drop_solve_graphs(h);
         if (h->cap_stream) (void) hipStreamDestroy(h->cap_stream);
+        h->fj.destroy();
         void *ptrs[] = {D.meta, D.fdesc, D.sched, D.child_idx, D.rel_idx, D.st_idx, D.asm_src, D.asm_tgt, D.long_src,
                         D.sdesc, D.fasm_src, D.fasm_tgt, D.flong_src, D.q, D.ax, D.pool, D.dbuf, D.tbuf, D.cv, D.xp, D.status, h->d_lmap, h->d_umap, h->d_lx, h->d_ux};
         for (void *p : ptrs) if (p) (void) hipFree(p);

@@ -64,11 +64,24 @@ struct DeviceFactor {
     long long *tbuf = nullptr;    // diagnostics (CS3_PROFILE=1): 8 shader-clock stamps per front, schedule order
 };
 
+// Side streams and events used to run the independent launches of one tree level
+// as parallel branches (of the captured graph, or of real streams in eager mode).
+struct ForkJoin {
+    static constexpr int NSIDE = 3;
+    hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> events;
+    size_t next = 0;
+    hipError_t init();
+    void destroy();
+    hipError_t event(hipEvent_t *e);       // next event of the pool (grows on demand)
+    void rewind() { next = 0; }
+};
+
 hipError_t prepare_kernels();
 hipError_t launch_factor_levels(const DeviceFactor &D, const std::vector<LaunchGroup> &groups,
-                                double inv_tol, hipStream_t st);
+                                double inv_tol, hipStream_t st, ForkJoin &fj);
 hipError_t launch_solve_levels(const DeviceFactor &D, const std::vector<LaunchGroup> &groups,
-                               double *X, int nrhs, bool forward, hipStream_t st);
+                               double *X, int nrhs, bool forward, hipStream_t st, ForkJoin &fj);
 hipError_t launch_permute(const DeviceFactor &D, const double *src, double *dst, int nrhs, bool scatter,
                           hipStream_t st);
 hipError_t launch_extract(const double *vals, const long long *map, double *out, long long count,

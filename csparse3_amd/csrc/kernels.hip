@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "cs3_device.hpp"
 
@@ -1016,18 +1017,85 @@ hipError_t prepare_kernels()
     return hipSuccess;
 }
 
-hipError_t launch_factor_levels(const DeviceFactor &D, const std::vector<LaunchGroup> &groups,
-                                double inv_tol, hipStream_t st)
+hipError_t ForkJoin::init()
 {
+    for (int i = 0; i < NSIDE; ++i) {
+        hipError_t e = hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+void ForkJoin::destroy()
+{
+    for (int i = 0; i < NSIDE; ++i) if (side[i]) (void) hipStreamDestroy(side[i]);
+    for (hipEvent_t e : events) (void) hipEventDestroy(e);
+    events.clear();
+}
+
+hipError_t ForkJoin::event(hipEvent_t *out)
+{
+    if (next == events.size()) {
+        hipEvent_t e;
+        hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        if (rc != hipSuccess) return rc;
+        events.push_back(e);
+    }
+    *out = events[next++];
+    return hipSuccess;
+}
+
+// Run the launch groups of one tree level concurrently: the first on `st`, the others on side
+// streams that fork from `st` and join it again.  `launch(group, stream)` enqueues one group.
+template <class Launch>
+static hipError_t run_level(const std::vector<LaunchGroup> &groups, size_t g0, size_t g1, hipStream_t st,
+                            ForkJoin &fj, bool parallel, Launch launch)
+{
+    const size_t ng = g1 - g0;
+    if (ng <= 1) return ng ? launch(groups[g0], st) : hipSuccess;
+    if (!parallel) {
+        for (size_t i = g0; i < g1; ++i) { hipError_t e = launch(groups[i], st); if (e != hipSuccess) return e; }
+        return hipSuccess;
+    }
+    hipEvent_t fork;
+    hipError_t e = fj.event(&fork);
+    if (e != hipSuccess) return e;
+    if ((e = hipEventRecord(fork, st)) != hipSuccess) return e;
+    // the heaviest group (last: big fronts / block kernels sort last) stays on the main stream
+    std::vector<hipEvent_t> joins;
+    for (size_t i = 0; i + 1 < ng; ++i) {
+        hipStream_t s = fj.side[i % ForkJoin::NSIDE];
+        if (i < (size_t) ForkJoin::NSIDE) { if ((e = hipStreamWaitEvent(s, fork, 0)) != hipSuccess) return e; }
+        if ((e = launch(groups[g0 + i], s)) != hipSuccess) return e;
+    }
+    if ((e = launch(groups[g1 - 1], st)) != hipSuccess) return e;
+    for (size_t i = 0; i < std::min(ng - 1, (size_t) ForkJoin::NSIDE); ++i) {
+        hipEvent_t j;
+        if ((e = fj.event(&j)) != hipSuccess) return e;
+        if ((e = hipEventRecord(j, fj.side[i])) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(st, j, 0)) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_factor_levels(const DeviceFactor &D, const std::vector<LaunchGroup> &groups,
+                                double inv_tol, hipStream_t st, ForkJoin &fj)
+{
+    fj.rewind();
     if (D.vals_size > D.big_begin) {     // big-front buffers start from zero: the gather writes only touched entries
         hipError_t e = hipMemset2DAsync(D.pool + D.big_begin, (size_t) D.pool_size * sizeof(double), 0,
                                         (size_t) (D.vals_size - D.big_begin) * sizeof(double), (size_t) D.batch, st);
         if (e != hipSuccess) return e;
     }
-    for (const LaunchGroup &g : groups) {
-        hipError_t e = (D.kind == CS3_LU) ? launch_front_group<CS3_LU>(D, g, inv_tol, st)
-                                          : launch_front_group<CS3_CHOLESKY>(D, g, inv_tol, st);
+    for (size_t g0 = 0; g0 < groups.size(); ) {
+        size_t g1 = g0;
+        while (g1 < groups.size() && groups[g1].level == groups[g0].level) ++g1;
+        hipError_t e = run_level(groups, g0, g1, st, fj, true, [&](const LaunchGroup &g, hipStream_t s) {
+            return (D.kind == CS3_LU) ? launch_front_group<CS3_LU>(D, g, inv_tol, s)
+                                      : launch_front_group<CS3_CHOLESKY>(D, g, inv_tol, s);
+        });
         if (e != hipSuccess) return e;
+        g0 = g1;
     }
     return hipSuccess;
 }
@@ -1072,19 +1140,30 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
 }
 
 hipError_t launch_solve_levels(const DeviceFactor &D, const std::vector<LaunchGroup> &groups,
-                               double *X, int nrhs, bool forward, hipStream_t st)
+                               double *X, int nrhs, bool forward, hipStream_t st, ForkJoin &fj)
 {
+    fj.rewind();
+    // the sweeps' per-level launches are short: fork/join costs more than it hides (measured), so they stay in line
+    static const bool solve_parallel = getenv("CS3_SOLVE_FORK") && getenv("CS3_SOLVE_FORK")[0] == '1';
+    auto launch = [&](const LaunchGroup &g, hipStream_t s) {
+        return (D.kind == CS3_LU) ? launch_solve_group<CS3_LU>(D, g, X, nrhs, forward, s)
+                                  : launch_solve_group<CS3_CHOLESKY>(D, g, X, nrhs, forward, s);
+    };
     if (forward) {
-        for (size_t gi = 0; gi < groups.size(); ++gi) {
-            hipError_t e = (D.kind == CS3_LU) ? launch_solve_group<CS3_LU>(D, groups[gi], X, nrhs, true, st)
-                                              : launch_solve_group<CS3_CHOLESKY>(D, groups[gi], X, nrhs, true, st);
+        for (size_t g0 = 0; g0 < groups.size(); ) {
+            size_t g1 = g0;
+            while (g1 < groups.size() && groups[g1].level == groups[g0].level) ++g1;
+            hipError_t e = run_level(groups, g0, g1, st, fj, solve_parallel, launch);
             if (e != hipSuccess) return e;
+            g0 = g1;
         }
     } else {
-        for (size_t gi = groups.size(); gi-- > 0; ) {
-            hipError_t e = (D.kind == CS3_LU) ? launch_solve_group<CS3_LU>(D, groups[gi], X, nrhs, false, st)
-                                              : launch_solve_group<CS3_CHOLESKY>(D, groups[gi], X, nrhs, false, st);
+        for (size_t g1 = groups.size(); g1 > 0; ) {
+            size_t g0 = g1;
+            while (g0 > 0 && groups[g0 - 1].level == groups[g1 - 1].level) --g0;
+            hipError_t e = run_level(groups, g0, g1, st, fj, solve_parallel, launch);
             if (e != hipSuccess) return e;
+            g1 = g0;
         }
     }
     return hipSuccess;

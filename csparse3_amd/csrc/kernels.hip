@@ -295,6 +295,108 @@ k_front_lds(const FrontDesc *__restrict__ fdesc, int first,
 #undef CS3_STAMP
 }
 
+// ---------------------------------------------- front owned by ONE wave ----
+// Fronts of order r <= NC <= 64: lane i keeps ROW i of the front in NC registers, so a pivot
+// needs no barrier and no LDS: the pivot row is read lane-to-scalar (v_readlane) and each lane
+// updates its own row.  Register indices must be static, so pivots are taken 8 at a time from
+// registers 0..7 (unrolled); the 8 finished columns are stored and the row is shifted down by 8,
+// which keeps "register j = column kb + j".  LDS is only the target of the assembly gather.
+template <int KIND, int NC>
+__global__ void __launch_bounds__(64)
+k_front_wave(const FrontDesc *__restrict__ fdesc, int first,
+             const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
+             const double *__restrict__ ax_all, double *__restrict__ pool_all,
+             long long nnz_a, long long pool_stride, double inv_tol, int *status)
+{
+    extern __shared__ __attribute__((aligned(16))) double F[];
+    constexpr int PB = 8;
+    const FrontDesc d = fdesc[first + blockIdx.x];
+    const double *ax = ax_all + (long long) blockIdx.y * nnz_a;
+    double *pool = pool_all + (long long) blockIdx.y * pool_stride;
+    const int r = d.r, w = d.w, nb = r - w;
+    const int ld = r | 1;
+    const int lane = threadIdx.x;
+    for (int i = lane; i < r * ld; i += 64) F[i] = 0.0;
+    __syncthreads();
+    gather_front(d.asm_begin, d.asm_count >> 6, 0, GATHER_UNROLL, asm_src, asm_tgt, long_src,
+                 [&](int q) -> const double * { return (q >= 0) ? pool + q : ax + ~q; },
+                 [&](int t, double v) { F[t] = v; });
+    __syncthreads();
+    double row[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) row[j] = (lane < r && j < r) ? F[lane + j * ld] : 0.0;
+
+    double *L = pool + d.lpan;
+    double *U = pool + d.upan;
+    double *cb = pool + d.cb;
+    const bool has_parent = d.parent >= 0;
+    // column `col` of the front, my entry v: panel, U panel or contribution block
+    auto put = [&](int col, double v) {
+        if (col >= r || lane >= r) return;
+        if (col < w) {
+            if (KIND == CS3_LU || lane >= col) L[lane + (long long) col * r] = v;
+        } else if (lane < w) {
+            if (KIND == CS3_LU) U[(col - w) + (long long) lane * nb] = v;
+        } else if (has_parent) {
+            if (KIND == CS3_LU || lane >= col) cb[(lane - w) + (long long) (col - w) * nb] = v;
+        }
+    };
+    int kb = 0;
+    for (; kb < w; kb += PB) {
+#pragma unroll
+        for (int kk = 0; kk < PB; ++kk) {
+            const int k = kb + kk;
+            if (k < w) {                                        // wave-uniform
+                const double piv = bcast_lane(row[kk], k);
+                const bool below = lane > k;
+                if (KIND == CS3_LU) {
+                    const double l = row[kk] / piv;
+                    if (below) {
+                        row[kk] = l;
+                        if (lane < r && !(fabs(l) <= inv_tol)) flag_column(status, d.c0 + k);
+                    }
+                    if (lane == k && (!(fabs(piv) > 0.0) || !(fabs(piv) < 1.0e300))) flag_column(status, d.c0 + k);
+#pragma unroll
+                    for (int j0 = kk + 1; j0 < NC; j0 += 4) {
+                        if (kb + j0 < r) {                      // skip register groups beyond the front
+#pragma unroll
+                            for (int j = j0; j < j0 + 4 && j < NC; ++j) {
+                                const double u = bcast_lane(row[j], k);
+                                if (below) row[j] -= l * u;
+                            }
+                        }
+                    }
+                } else {
+                    const double dg = sqrt(piv);
+                    const double l = row[kk] / dg;
+                    if (below) row[kk] = l;
+                    if (lane == k) {
+                        row[kk] = (piv > 0.0) ? dg : -1.0;
+                        if (!(piv > 0.0)) flag_column(status, d.c0 + k);
+                    }
+#pragma unroll
+                    for (int j0 = kk + 1; j0 < NC; j0 += 4) {
+                        if (kb + j0 < r) {
+#pragma unroll
+                            for (int j = j0; j < j0 + 4 && j < NC; ++j) {
+                                const int col = min(kb + j, 63);
+                                const double lj = bcast_lane(row[kk], col);   // L(col, k): lane col, same register
+                                if (below && lane >= kb + j) row[j] -= l * lj;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < PB; ++kk) put(kb + kk, row[kk]);
+#pragma unroll
+        for (int j = 0; j < NC; ++j) row[j] = (j + PB < NC) ? row[j + PB] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < NC; ++j) put(kb + j, row[j]);
+}
+
 // ------------------------------------------- front too large for the LDS --
 // The front is one dense r x r column-major buffer in the pool (zeroed at the
 // start of the factorisation).  Per front: one gather launch, then per block
@@ -982,12 +1084,14 @@ static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g
     const size_t lds = (ld * (size_t) g.max_r + 4 * (size_t) g.max_r + 6) * sizeof(double);
 #define CS3_FRONT_ARGS D.fdesc, g.first, D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool, D.nnz_a, D.pool_size, inv_tol, D.status, D.tbuf
     switch (g.cls) {
+#define CS3_WAVE_ARGS D.fdesc, g.first, D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool, D.nnz_a, D.pool_size, inv_tol, D.status
     case FC_R16:
-        hipLaunchKernelGGL((k_front_lds<KIND, 64, 8, 2, 2>), grid, dim3(64), lds, st, CS3_FRONT_ARGS); break;
+        hipLaunchKernelGGL((k_front_wave<KIND, 16>), grid, dim3(64), lds, st, CS3_WAVE_ARGS); break;
     case FC_R32:
-        hipLaunchKernelGGL((k_front_lds<KIND, 64, 8, 4, 4>), grid, dim3(64), lds, st, CS3_FRONT_ARGS); break;
+        hipLaunchKernelGGL((k_front_wave<KIND, 32>), grid, dim3(64), lds, st, CS3_WAVE_ARGS); break;
     case FC_R64:
         hipLaunchKernelGGL((k_front_lds<KIND, 256, 16, 4, 4>), grid, dim3(256), lds, st, CS3_FRONT_ARGS); break;
+#undef CS3_WAVE_ARGS
     default:
         hipLaunchKernelGGL((k_front_lds<KIND, 512, 32, 5, 9>), grid, dim3(512), lds, st, CS3_FRONT_ARGS); break;
     }

@@ -299,6 +299,9 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     double relax_z = 0.5; i64 relax_w = 8;
     if (const char *e = std::getenv("CS3_RELAX_Z")) relax_z = std::atof(e);
     if (const char *e = std::getenv("CS3_RELAX_W")) relax_w = std::atoll(e);
+    i64 relax_r = 32; double relax_z2 = 0.25;          // fronts beyond the one-wave kernels (r > 32) merge only when nearly free
+    if (const char *e = std::getenv("CS3_RELAX_R")) relax_r = std::atoll(e);
+    if (const char *e = std::getenv("CS3_RELAX_Z2")) relax_z2 = std::atof(e);
     std::vector<i64> mw(nf), mr(nf), mc0(nf);
     std::vector<double> mz(nf, 0.0);
     std::vector<char> alive(nf, 1);
@@ -314,6 +317,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         const double tn = (double) wn * (double) rn - 0.5 * (double) wn * (double) (wn - 1);
         bool ok = (wn <= relax_w) || (zn <= relax_z * tn);
         if (rn > lds_r && std::max(mr[s], mr[p]) <= lds_r) ok = false;   // do not push a resident front out of the LDS
+        if (rn > relax_r && rn <= lds_r && wn > relax_w && zn > relax_z2 * tn) ok = false;
         if (!ok) continue;
         mw[p] = wn; mr[p] = rn; mz[p] = zn; mc0[p] = mc0[s]; alive[s] = 0;
     }

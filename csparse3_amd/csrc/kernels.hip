@@ -302,46 +302,62 @@ k_front_lds(const FrontDesc *__restrict__ fdesc, int first,
 // registers 0..7 (unrolled); the 8 finished columns are stored and the row is shifted down by 8,
 // which keeps "register j = column kb + j".  LDS is only the target of the assembly gather.
 template <int KIND, int NC>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 k_front_wave(const FrontDesc *__restrict__ fdesc, int first,
              const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
              const double *__restrict__ ax_all, double *__restrict__ pool_all,
-             long long nnz_a, long long pool_stride, double inv_tol, int *status)
+             long long nnz_a, long long pool_stride, double inv_tol, int *status, long long *tbuf)
 {
     extern __shared__ __attribute__((aligned(16))) double F[];
     constexpr int PB = 8;
+    const long long t_start = tbuf ? (long long) __builtin_amdgcn_s_memtime() : 0;
+#define CS3_STAMP(p) do { if (tbuf && threadIdx.x == 0) tbuf[(long long) (first + blockIdx.x) * 8 + (p)] = (long long) __builtin_amdgcn_s_memtime() - t_start; } while (0)
     const FrontDesc d = fdesc[first + blockIdx.x];
     const double *ax = ax_all + (long long) blockIdx.y * nnz_a;
     double *pool = pool_all + (long long) blockIdx.y * pool_stride;
     const int r = d.r, w = d.w, nb = r - w;
     const int ld = r | 1;
-    const int lane = threadIdx.x;
-    for (int i = lane; i < r * ld; i += 64) F[i] = 0.0;
+    // four waves assemble the front (the gather is latency-bound: more loads in flight), one eliminates it
+    CS3_STAMP(0);
+    for (int i = threadIdx.x; i < r * ld; i += 256) F[i] = 0.0;
     __syncthreads();
-    gather_front(d.asm_begin, d.asm_count >> 6, 0, GATHER_UNROLL, asm_src, asm_tgt, long_src,
+    CS3_STAMP(1);
+    gather_front(d.asm_begin, d.asm_count >> 6, (threadIdx.x >> 6) * GATHER_UNROLL, 4 * GATHER_UNROLL,
+                 asm_src, asm_tgt, long_src,
                  [&](int q) -> const double * { return (q >= 0) ? pool + q : ax + ~q; },
                  [&](int t, double v) { F[t] = v; });
     __syncthreads();
+    CS3_STAMP(2);
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
     double row[NC];
+    {
+        const int li = lane < r ? lane : 0;             // unconditional LDS reads, then select
 #pragma unroll
-    for (int j = 0; j < NC; ++j) row[j] = (lane < r && j < r) ? F[lane + j * ld] : 0.0;
-
+        for (int j = 0; j < NC; ++j) {
+            const double v = F[li + (j < r ? j : 0) * ld];
+            row[j] = (lane < r && j < r) ? v : 0.0;
+        }
+    }
     double *L = pool + d.lpan;
     double *U = pool + d.upan;
     double *cb = pool + d.cb;
     const bool has_parent = d.parent >= 0;
-    // column `col` of the front, my entry v: panel, U panel or contribution block
+    const bool live = lane < r;
+    // where my entry of column `col` goes: panel, U panel or contribution block (one predicated store)
     auto put = [&](int col, double v) {
-        if (col >= r || lane >= r) return;
-        if (col < w) {
-            if (KIND == CS3_LU || lane >= col) L[lane + (long long) col * r] = v;
-        } else if (lane < w) {
-            if (KIND == CS3_LU) U[(col - w) + (long long) lane * nb] = v;
-        } else if (has_parent) {
-            if (KIND == CS3_LU || lane >= col) cb[(lane - w) + (long long) (col - w) * nb] = v;
-        }
+        const bool in_l = col < w, in_u = !in_l && lane < w;
+        double *dst = in_l ? L + (lane + (long long) col * r)
+                           : in_u ? U + ((col - w) + (long long) lane * nb)
+                                  : cb + ((lane - w) + (long long) (col - w) * nb);
+        bool ok = live && col < r && (in_l || in_u || has_parent);
+        if (KIND == CS3_CHOLESKY) ok = ok && !in_u && lane >= col;
+        if (ok) *dst = v;
     };
+    bool bad = false;
+    int bad_col = 0;
     int kb = 0;
+    CS3_STAMP(3);
     for (; kb < w; kb += PB) {
 #pragma unroll
         for (int kk = 0; kk < PB; ++kk) {
@@ -350,38 +366,34 @@ k_front_wave(const FrontDesc *__restrict__ fdesc, int first,
                 const double piv = bcast_lane(row[kk], k);
                 const bool below = lane > k;
                 if (KIND == CS3_LU) {
-                    const double l = row[kk] / piv;
-                    if (below) {
-                        row[kk] = l;
-                        if (lane < r && !(fabs(l) <= inv_tol)) flag_column(status, d.c0 + k);
-                    }
-                    if (lane == k && (!(fabs(piv) > 0.0) || !(fabs(piv) < 1.0e300))) flag_column(status, d.c0 + k);
+                    const double l = below ? row[kk] / piv : 0.0;   // multiplier, zero on and above the pivot row
+                    if (below) row[kk] = l;
+                    const bool rej = (live && !(fabs(l) <= inv_tol)) ||
+                                     (lane == k && (!(fabs(piv) > 0.0) || !(fabs(piv) < 1.0e300)));
+                    if (rej && !bad) { bad = true; bad_col = k; }
 #pragma unroll
-                    for (int j0 = kk + 1; j0 < NC; j0 += 4) {
+                    for (int j0 = kk + 1; j0 < NC; j0 += 8) {
                         if (kb + j0 < r) {                      // skip register groups beyond the front
 #pragma unroll
-                            for (int j = j0; j < j0 + 4 && j < NC; ++j) {
-                                const double u = bcast_lane(row[j], k);
-                                if (below) row[j] -= l * u;
-                            }
+                            for (int j = j0; j < j0 + 8 && j < NC; ++j) row[j] -= l * bcast_lane(row[j], k);
                         }
                     }
                 } else {
                     const double dg = sqrt(piv);
-                    const double l = row[kk] / dg;
+                    const double l = below ? row[kk] / dg : 0.0;
                     if (below) row[kk] = l;
                     if (lane == k) {
                         row[kk] = (piv > 0.0) ? dg : -1.0;
-                        if (!(piv > 0.0)) flag_column(status, d.c0 + k);
+                        if (!(piv > 0.0) && !bad) { bad = true; bad_col = k; }
                     }
 #pragma unroll
-                    for (int j0 = kk + 1; j0 < NC; j0 += 4) {
+                    for (int j0 = kk + 1; j0 < NC; j0 += 8) {
                         if (kb + j0 < r) {
 #pragma unroll
-                            for (int j = j0; j < j0 + 4 && j < NC; ++j) {
+                            for (int j = j0; j < j0 + 8 && j < NC; ++j) {
                                 const int col = min(kb + j, 63);
                                 const double lj = bcast_lane(row[kk], col);   // L(col, k): lane col, same register
-                                if (below && lane >= kb + j) row[j] -= l * lj;
+                                row[j] -= (lane >= kb + j ? l : 0.0) * lj;
                             }
                         }
                     }
@@ -393,8 +405,12 @@ k_front_wave(const FrontDesc *__restrict__ fdesc, int first,
 #pragma unroll
         for (int j = 0; j < NC; ++j) row[j] = (j + PB < NC) ? row[j + PB] : 0.0;
     }
+    CS3_STAMP(4);
 #pragma unroll
     for (int j = 0; j < NC; ++j) put(kb + j, row[j]);
+    if (bad) flag_column(status, d.c0 + bad_col);
+    CS3_STAMP(5);
+#undef CS3_STAMP
 }
 
 // ------------------------------------------- front too large for the LDS --
@@ -1084,11 +1100,11 @@ static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g
     const size_t lds = (ld * (size_t) g.max_r + 4 * (size_t) g.max_r + 6) * sizeof(double);
 #define CS3_FRONT_ARGS D.fdesc, g.first, D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool, D.nnz_a, D.pool_size, inv_tol, D.status, D.tbuf
     switch (g.cls) {
-#define CS3_WAVE_ARGS D.fdesc, g.first, D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool, D.nnz_a, D.pool_size, inv_tol, D.status
+#define CS3_WAVE_ARGS D.fdesc, g.first, D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool, D.nnz_a, D.pool_size, inv_tol, D.status, D.tbuf
     case FC_R16:
-        hipLaunchKernelGGL((k_front_wave<KIND, 16>), grid, dim3(64), lds, st, CS3_WAVE_ARGS); break;
+        hipLaunchKernelGGL((k_front_wave<KIND, 16>), grid, dim3(256), lds, st, CS3_WAVE_ARGS); break;
     case FC_R32:
-        hipLaunchKernelGGL((k_front_wave<KIND, 32>), grid, dim3(64), lds, st, CS3_WAVE_ARGS); break;
+        hipLaunchKernelGGL((k_front_wave<KIND, 32>), grid, dim3(256), lds, st, CS3_WAVE_ARGS); break;
     case FC_R64:
         hipLaunchKernelGGL((k_front_lds<KIND, 256, 16, 4, 4>), grid, dim3(256), lds, st, CS3_FRONT_ARGS); break;
 #undef CS3_WAVE_ARGS

@@ -172,16 +172,13 @@ __device__ __forceinline__ void flag_column(int *status, int col)
 // block being read and written there.  Results go back through the LDS image
 // so that the stores to the panels are row-contiguous.
 template <int KIND, int THREADS, int TX, int RI, int RJ>
-__global__ void __launch_bounds__(THREADS)
-k_front_lds(const FrontDesc *__restrict__ fdesc, int first,
-            const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
-            const double *__restrict__ ax_all, double *__restrict__ pool_all,
-            long long nnz_a, long long pool_stride, double inv_tol, int *status, long long *tbuf)
+__device__ __forceinline__ void
+front_lds_body(const FrontDesc &d, int first, double *F,
+               const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
+               const double *__restrict__ ax_all, double *__restrict__ pool_all,
+               long long nnz_a, long long pool_stride, double inv_tol, int *status, long long *tbuf, long long t_start)
 {
-    extern __shared__ __attribute__((aligned(16))) double F[];
     constexpr int TY = THREADS / TX;
-    const long long t_start = tbuf ? (long long) __builtin_amdgcn_s_memtime() : 0;
-    const FrontDesc d = fdesc[first + blockIdx.x];
 #define CS3_STAMP(p) do { if (tbuf && threadIdx.x == 0) tbuf[(long long) (first + blockIdx.x) * 8 + (p)] = (long long) __builtin_amdgcn_s_memtime() - t_start; } while (0)
     const double *ax = ax_all + (long long) blockIdx.y * nnz_a;
     double *pool = pool_all + (long long) blockIdx.y * pool_stride;
@@ -295,6 +292,20 @@ k_front_lds(const FrontDesc *__restrict__ fdesc, int first,
 #undef CS3_STAMP
 }
 
+template <int KIND, int THREADS, int TX, int RI, int RJ>
+__global__ void __launch_bounds__(THREADS)
+k_front_lds(const FrontDesc *__restrict__ fdesc, int first,
+            const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
+            const double *__restrict__ ax_all, double *__restrict__ pool_all,
+            long long nnz_a, long long pool_stride, double inv_tol, int *status, long long *tbuf)
+{
+    extern __shared__ __attribute__((aligned(16))) double F[];
+    const long long t_start = tbuf ? (long long) __builtin_amdgcn_s_memtime() : 0;
+    const FrontDesc d = fdesc[first + blockIdx.x];
+    front_lds_body<KIND, THREADS, TX, RI, RJ>(d, first, F, asm_src, asm_tgt, long_src, ax_all, pool_all, nnz_a,
+                                              pool_stride, inv_tol, status, tbuf, t_start);
+}
+
 // ---------------------------------------------- front owned by ONE wave ----
 // Fronts of order r <= NC <= 64: lane i keeps ROW i of the front in NC registers, so a pivot
 // needs no barrier and no LDS: the pivot row is read lane-to-scalar (v_readlane) and each lane
@@ -302,17 +313,14 @@ k_front_lds(const FrontDesc *__restrict__ fdesc, int first,
 // registers 0..7 (unrolled); the 8 finished columns are stored and the row is shifted down by 8,
 // which keeps "register j = column kb + j".  LDS is only the target of the assembly gather.
 template <int KIND, int NC>
-__global__ void __launch_bounds__(256)
-k_front_wave(const FrontDesc *__restrict__ fdesc, int first,
-             const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
-             const double *__restrict__ ax_all, double *__restrict__ pool_all,
-             long long nnz_a, long long pool_stride, double inv_tol, int *status, long long *tbuf)
+__device__ __forceinline__ void
+front_wave_body(const FrontDesc &d, int first, double *F,
+                const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
+                const double *__restrict__ ax_all, double *__restrict__ pool_all,
+                long long nnz_a, long long pool_stride, double inv_tol, int *status, long long *tbuf, long long t_start)
 {
-    extern __shared__ __attribute__((aligned(16))) double F[];
     constexpr int PB = 8;
-    const long long t_start = tbuf ? (long long) __builtin_amdgcn_s_memtime() : 0;
 #define CS3_STAMP(p) do { if (tbuf && threadIdx.x == 0) tbuf[(long long) (first + blockIdx.x) * 8 + (p)] = (long long) __builtin_amdgcn_s_memtime() - t_start; } while (0)
-    const FrontDesc d = fdesc[first + blockIdx.x];
     const double *ax = ax_all + (long long) blockIdx.y * nnz_a;
     double *pool = pool_all + (long long) blockIdx.y * pool_stride;
     const int r = d.r, w = d.w, nb = r - w;
@@ -411,6 +419,26 @@ k_front_wave(const FrontDesc *__restrict__ fdesc, int first,
     if (bad) flag_column(status, d.c0 + bad_col);
     CS3_STAMP(5);
 #undef CS3_STAMP
+}
+
+// Every front of order <= 64 in one launch: one wave eliminates the small ones (r <= 32), the
+// 16 x 16 thread grid the others.  One launch instead of two per tree level.
+template <int KIND>
+__global__ void __launch_bounds__(256)
+k_front_mix(const FrontDesc *__restrict__ fdesc, int first,
+            const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
+            const double *__restrict__ ax_all, double *__restrict__ pool_all,
+            long long nnz_a, long long pool_stride, double inv_tol, int *status, long long *tbuf)
+{
+    extern __shared__ __attribute__((aligned(16))) double F[];
+    const long long t_start = tbuf ? (long long) __builtin_amdgcn_s_memtime() : 0;
+    const FrontDesc d = fdesc[first + blockIdx.x];
+    if (d.r <= 32)
+        front_wave_body<KIND, 32>(d, first, F, asm_src, asm_tgt, long_src, ax_all, pool_all, nnz_a, pool_stride,
+                                  inv_tol, status, tbuf, t_start);
+    else
+        front_lds_body<KIND, 256, 16, 4, 4>(d, first, F, asm_src, asm_tgt, long_src, ax_all, pool_all, nnz_a,
+                                            pool_stride, inv_tol, status, tbuf, t_start);
 }
 
 // ------------------------------------------- front too large for the LDS --
@@ -1100,14 +1128,10 @@ static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g
     const size_t lds = (ld * (size_t) g.max_r + 4 * (size_t) g.max_r + 6) * sizeof(double);
 #define CS3_FRONT_ARGS D.fdesc, g.first, D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool, D.nnz_a, D.pool_size, inv_tol, D.status, D.tbuf
     switch (g.cls) {
-#define CS3_WAVE_ARGS D.fdesc, g.first, D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool, D.nnz_a, D.pool_size, inv_tol, D.status, D.tbuf
     case FC_R16:
-        hipLaunchKernelGGL((k_front_wave<KIND, 16>), grid, dim3(256), lds, st, CS3_WAVE_ARGS); break;
     case FC_R32:
-        hipLaunchKernelGGL((k_front_wave<KIND, 32>), grid, dim3(256), lds, st, CS3_WAVE_ARGS); break;
     case FC_R64:
-        hipLaunchKernelGGL((k_front_lds<KIND, 256, 16, 4, 4>), grid, dim3(256), lds, st, CS3_FRONT_ARGS); break;
-#undef CS3_WAVE_ARGS
+        hipLaunchKernelGGL((k_front_mix<KIND>), grid, dim3(256), lds, st, CS3_FRONT_ARGS); break;
     default:
         hipLaunchKernelGGL((k_front_lds<KIND, 512, 32, 5, 9>), grid, dim3(512), lds, st, CS3_FRONT_ARGS); break;
     }

@@ -109,9 +109,7 @@ double seconds_since(std::chrono::steady_clock::time_point t0)
 
 int front_class(i64 r)
 {
-    if (r <= 16) return FC_R16;
-    if (r <= 32) return FC_R32;
-    if (r <= 64) return FC_R64;
+    if (r <= 64) return FC_R64;       // one launch: k_front_mix (one wave for r <= 32, 16 x 16 threads above)
     if (r <= 136) return FC_LDS;      // (136*137 + 4*136 + 6) doubles = 153 KB of the 160 KB LDS
     return FC_BIG;
 }

@@ -191,8 +191,8 @@ def main():
                        "max_front": int(info.max_front), "ordering": "amd(A+A')",
                        "parallelism": "independent matrices per rank, no collective"},
             "roofline": {"bound": "hbm",
-                         "kernel": "numeric factorisation = one hipGraph of k_front_lds / k_big_gather / k_big_step "
-                                   "launches (one per tree level and size class, one per 32 pivots of a big front)",
+                         "kernel": "numeric factorisation = one hipGraph of k_front_mix / k_front_lds / k_big_gather / "
+                                   "k_big_step launches (per tree level; one per 32 pivots of a big front)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "frac_of_measured_peak": achieved / HBM_MEASURED_GBS,

@@ -76,6 +76,7 @@ int ensure_device(cs3_handle h)
     DeviceFactor &D = h->D;
     D.kind = S.kind; D.n = S.n; D.nnz_a = S.nnzA; D.batch = h->batch;
     D.vals_size = S.vals_size; D.pool_size = S.pool_size; D.cv_size = S.cv_size; D.big_begin = S.big_begin;
+    D.bv_size = S.bv_size;
     std::vector<FrontMeta> meta(S.nsuper);
     for (i32 s = 0; s < S.nsuper; ++s) {
         FrontMeta &m = meta[s];
@@ -110,6 +111,7 @@ int ensure_device(cs3_handle h)
         SolveDesc &f = sdesc[t];
         f.lpan = S.lpan_off[s]; f.upan = S.upan_off[s]; f.cv = S.cv_off[s]; f.st = S.st_ptr[s];
         f.fasm_begin = S.fasm_ptr[s]; f.fasm_count = (int) (S.fasm_ptr[s + 1] - S.fasm_ptr[s]);
+        f.bv = S.bv_off[s];
         f.c0 = S.sn_ptr[s];
         f.r = (int) (S.st_ptr[s + 1] - S.st_ptr[s]);
         f.w = S.sn_ptr[s + 1] - S.sn_ptr[s];
@@ -157,9 +159,11 @@ int ensure_rhs_capacity(cs3_handle h, long long nrhs)
     drop_solve_graphs(h);
     if (D.cv) (void) hipFree(D.cv);
     if (D.xp) (void) hipFree(D.xp);
-    D.cv = D.xp = nullptr;
+    if (D.bigv) (void) hipFree(D.bigv);
+    D.cv = D.xp = D.bigv = nullptr;
     CS3_HIP(hipMalloc((void **) &D.cv, std::max<size_t>(1, (size_t) (D.batch * D.cv_size * nrhs)) * sizeof(double)));
     CS3_HIP(hipMalloc((void **) &D.xp, std::max<size_t>(1, (size_t) (D.batch * D.n * nrhs)) * sizeof(double)));
+    CS3_HIP(hipMalloc((void **) &D.bigv, std::max<size_t>(1, (size_t) (D.batch * D.bv_size * nrhs)) * sizeof(double)));
     D.nrhs_cap = nrhs;
     return CS3_OK;
 }
@@ -351,7 +355,7 @@ int cs3_free(cs3_handle h)
         if (h->cap_stream) (void) hipStreamDestroy(h->cap_stream);
         h->fj.destroy();
         void *ptrs[] = {D.meta, D.fdesc, D.sched, D.child_idx, D.rel_idx, D.st_idx, D.asm_src, D.asm_tgt, D.long_src,
-                        D.sdesc, D.fasm_src, D.fasm_tgt, D.flong_src, D.q, D.ax, D.pool, D.dbuf, D.tbuf, D.cv, D.xp, D.status, h->d_lmap, h->d_umap, h->d_lx, h->d_ux};
+                        D.sdesc, D.fasm_src, D.fasm_tgt, D.flong_src, D.q, D.ax, D.pool, D.dbuf, D.tbuf, D.bigv, D.cv, D.xp, D.status, h->d_lmap, h->d_umap, h->d_lx, h->d_ux};
         for (void *p : ptrs) if (p) (void) hipFree(p);
     }
     delete h;

@@ -34,6 +34,7 @@ struct FrontDesc {
 // What the solve kernels read per front, in SOLVE-schedule order.
 struct SolveDesc {
     long long lpan, upan, cv, st, fasm_begin;
+    long long bv;                 // kind-2 fronts: offset of the full front vector in bigv
     int fasm_count;
     int c0, r, w;
     int u_sk, u_sj;               // U(k, j) = pool[upan + k*u_sk + (j-w)*u_sj]
@@ -59,6 +60,8 @@ struct DeviceFactor {
     long long dbuf_size = 0;
     double *cv = nullptr;         // [batch][cv_size * nrhs_cap]
     double *xp = nullptr;         // [batch][n * nrhs_cap] right-hand sides in pivot order
+    double *bigv = nullptr;       // [batch][nrhs_cap][bv_size] front vectors of the wide big fronts
+    long long bv_size = 0;
     long long nrhs_cap = 0;
     int *status = nullptr;        // [1] first failing pivot column, 0x7f7f7f7f when clean
     long long *tbuf = nullptr;    // diagnostics (CS3_PROFILE=1): 8 shader-clock stamps per front, schedule order

@@ -80,8 +80,11 @@ struct Symbolic {
     std::vector<i64> fasm_ptr;
     std::vector<i32> fasm_src, fasm_tgt, flong_src;
     // solve schedule: supernodes by (level, kind); kind 0 = one wave per front
-    // (r <= 128, w <= 64), kind 1 = one workgroup per front
+    // (r <= 128, w <= 64), kind 1 = one workgroup per front, kind 2 = wide big fronts
+    // (w > 64, r > 136): one launch per 64-column chunk, many workgroups
     std::vector<i32> ssched;
+    std::vector<i64> bv_off;                  // kind-2 fronts: offset of their full front vector in the bigv buffer
+    i64 bv_size = 0;
     std::vector<LaunchGroup> sgroups;
     // schedule
     i32 nlevels = 0;

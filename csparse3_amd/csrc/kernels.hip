@@ -1012,6 +1012,199 @@ k_bwd_blk(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ s
     for (int i = tid; i < w; i += 256) X[(long long) (d.c0 + i) * nrhs + rhs] = v[i];
 }
 
+// Wide big fronts (w > 64, r > 136): the single-workgroup sweep above is bound by what one CU
+// can pull from memory, so these fronts take ONE LAUNCH PER 64-COLUMN CHUNK with many
+// workgroups, as the factorisation does: the front vector lives in HBM (bigv); in chunk launch c
+// every workgroup solves the 64 x 64 triangle of the chunk on its own (wave 0, rows in registers)
+// and then applies the chunk to ITS slice of 64 rows (4 threads per row, 16 columns each,
+// partial sums combined in a fixed order).  blockIdx.y = matrix * nrhs + right-hand side.
+__global__ void __launch_bounds__(256)
+k_fwd_big_gather(const SolveDesc *__restrict__ sd, int first,
+                 const int *__restrict__ fsrc, const int *__restrict__ ftgt, const int *__restrict__ flong,
+                 const double *__restrict__ cv_all, const double *__restrict__ X_all, double *__restrict__ bigv_all,
+                 int nrhs, long long cv_stride, long long x_stride, long long bv_size)
+{
+    const SolveDesc d = sd[first + blockIdx.z];
+    const int b = blockIdx.y / nrhs, rhs = blockIdx.y % nrhs;
+    const double *cv = cv_all + (long long) b * cv_stride;
+    const double *X = X_all + (long long) b * x_stride;
+    double *v = bigv_all + ((long long) b * nrhs + rhs) * bv_size + d.bv;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // rows without any source (none in practice: every row has X or a child) keep what the init wrote
+    gather_front(d.fasm_begin, d.fasm_count >> 6, wave * GATHER_UNROLL, gridDim.x * 4 * GATHER_UNROLL, fsrc, ftgt, flong,
+                 [&](int q) -> const double * {
+                     return (q >= 0) ? cv + (long long) q * nrhs + rhs : X + (long long) (~q) * nrhs + rhs;
+                 },
+                 [&](int t, double val) { v[t] = val; });
+}
+
+// Triangle of chunk [kb, kb + bw) by wave 0: lane = row kb + lane.  lower: unit lower L (forward),
+// else upper U with its diagonal (backward).  y[] (LDS) receives the chunk's solution.
+template <int KIND, bool FORWARD>
+__device__ __forceinline__ void big_triangle(const double *__restrict__ L, long long r, int kb, int bw,
+                                             const double *__restrict__ v, double *y)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = kb + lane;
+    double t[SOLVE_BW];
+#pragma unroll
+    for (int j = 0; j < SOLVE_BW; ++j) {
+        long long off;
+        bool need;
+        if (FORWARD) { off = (long long) i + (long long) (kb + j) * r; need = lane >= j; }
+        else {
+            off = (KIND == CS3_LU) ? (long long) i + (long long) (kb + j) * r : (long long) (kb + j) + (long long) i * r;
+            need = lane <= j;
+        }
+        t[j] = load_if(L, off, j < bw && lane < bw && need);
+    }
+    double vi = load_if(v, i, lane < bw);
+    if (FORWARD) {
+#pragma unroll
+        for (int j = 0; j < SOLVE_BW; ++j) {
+            if (j < bw) {
+                if (KIND == CS3_CHOLESKY && lane == j) vi /= t[j];
+                const double xk = bcast_lane(vi, j);
+                if (lane > j) vi -= t[j] * xk;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int jj = 0; jj < SOLVE_BW; ++jj) {
+            const int j = SOLVE_BW - 1 - jj;
+            if (j < bw) {
+                if (lane == j) vi /= t[j];
+                const double xk = bcast_lane(vi, j);
+                if (lane < j) vi -= t[j] * xk;
+            }
+        }
+    }
+    if (lane < bw) y[lane] = vi;
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256)
+k_fwd_big_step(const SolveDesc *__restrict__ sd, int first, int kb,
+               const double *__restrict__ pool_all, double *__restrict__ cv_all, double *__restrict__ X_all,
+               double *__restrict__ bigv_all, int nrhs, long long pool_stride, long long cv_stride,
+               long long x_stride, long long bv_size)
+{
+    __shared__ double y[SOLVE_BW];
+    __shared__ double part[4][64];
+    const SolveDesc d = sd[first + blockIdx.z];
+    const int r = d.r, w = d.w;
+    if (kb >= w) return;
+    const int bw = min(SOLVE_BW, w - kb), ke = kb + bw;
+    const int nsl = (r - ke + 63) / 64;
+    if ((int) blockIdx.x > 0 && (int) blockIdx.x >= nsl) return;
+    const int b = blockIdx.y / nrhs, rhs = blockIdx.y % nrhs;
+    const double *L = pool_all + (long long) b * pool_stride + d.lpan;
+    double *v = bigv_all + ((long long) b * nrhs + rhs) * bv_size + d.bv;
+    const int tid = threadIdx.x;
+    if (tid < 64) big_triangle<KIND, true>(L, r, kb, bw, v, y);
+    __syncthreads();
+    if (blockIdx.x == 0 && tid < bw)
+        X_all[(long long) b * x_stride + (long long) (d.c0 + kb + tid) * nrhs + rhs] = y[tid];
+    // my slice of rows below the chunk
+    const int row = ke + blockIdx.x * 64 + (tid & 63), quarter = tid >> 6;
+    double acc = 0.0;
+    if (row < r) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int jj = quarter * 16 + j;
+            acc += load_if(L, (long long) row + (long long) (kb + jj) * r, jj < bw) * y[jj < bw ? jj : 0];
+        }
+    }
+    part[quarter][tid & 63] = acc;
+    __syncthreads();
+    if (tid < 64 && row < r) {
+        const double nv = v[row] - (((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid]);
+        v[row] = nv;
+        if (ke >= w && row >= w && d.parent >= 0)           // last chunk: rows below the pivots are final
+            cv_all[(long long) b * cv_stride + (d.cv + row - w) * nrhs + rhs] = nv;
+    }
+}
+
+// v = [X rows of my pivots ; X rows of my ancestors], pivot rows minus U12 times the ancestors.
+template <int KIND>
+__global__ void __launch_bounds__(256)
+k_bwd_big_init(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ st_idx,
+               const double *__restrict__ pool_all, const double *__restrict__ X_all, double *__restrict__ bigv_all,
+               int nrhs, long long pool_stride, long long x_stride, long long bv_size)
+{
+    extern __shared__ __attribute__((aligned(16))) double v2[];      // [nb]
+    const SolveDesc d = sd[first + blockIdx.z];
+    const int b = blockIdx.y / nrhs, rhs = blockIdx.y % nrhs;
+    const int r = d.r, w = d.w, nb = r - w;
+    const double *pool = pool_all + (long long) b * pool_stride;
+    const double *X = X_all + (long long) b * x_stride;
+    double *v = bigv_all + ((long long) b * nrhs + rhs) * bv_size + d.bv;
+    const int *st = st_idx + d.st;
+    const int tid = threadIdx.x;
+    for (int j = tid; j < nb; j += 256) v2[j] = X[(long long) st[w + j] * nrhs + rhs];
+    __syncthreads();
+    const double *L = pool + d.lpan;
+    const double *U = pool + d.upan;
+    // one pivot row per thread; for a fixed ancestor column the rows are contiguous in memory
+    for (int i = blockIdx.x * 256 + tid; i < w; i += gridDim.x * 256) {
+        double acc = 0.0;
+        for (int j0 = 0; j0 < nb; j0 += 16) {
+            double u[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int jj = j0 + j;
+                const long long off = (KIND == CS3_LU) ? (long long) i * d.u_sk + (long long) jj * d.u_sj
+                                                       : (long long) (w + jj) + (long long) i * r;
+                u[j] = load_if((KIND == CS3_LU) ? U : L, off, jj < nb);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc += u[j] * v2[j0 + j < nb ? j0 + j : 0];
+        }
+        v[i] = X[(long long) (d.c0 + i) * nrhs + rhs] - acc;
+    }
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256)
+k_bwd_big_step(const SolveDesc *__restrict__ sd, int first, int chunk_from_right,
+               const double *__restrict__ pool_all, double *__restrict__ X_all, double *__restrict__ bigv_all,
+               int nrhs, long long pool_stride, long long x_stride, long long bv_size)
+{
+    __shared__ double y[SOLVE_BW];
+    __shared__ double part[4][64];
+    const SolveDesc d = sd[first + blockIdx.z];
+    const int r = d.r, w = d.w;
+    const int nchunk = (w + SOLVE_BW - 1) / SOLVE_BW;
+    const int c = nchunk - 1 - chunk_from_right;
+    if (c < 0) return;
+    const int kb = c * SOLVE_BW, bw = min(SOLVE_BW, w - kb);
+    const int nsl = (kb + 63) / 64;                        // slices of rows above the chunk
+    if ((int) blockIdx.x > 0 && (int) blockIdx.x >= nsl) return;
+    const int b = blockIdx.y / nrhs, rhs = blockIdx.y % nrhs;
+    const double *L = pool_all + (long long) b * pool_stride + d.lpan;
+    double *v = bigv_all + ((long long) b * nrhs + rhs) * bv_size + d.bv;
+    const int tid = threadIdx.x;
+    if (tid < 64) big_triangle<KIND, false>(L, r, kb, bw, v, y);
+    __syncthreads();
+    if (blockIdx.x == 0 && tid < bw)
+        X_all[(long long) b * x_stride + (long long) (d.c0 + kb + tid) * nrhs + rhs] = y[tid];
+    const int row = blockIdx.x * 64 + (tid & 63), quarter = tid >> 6;
+    double acc = 0.0;
+    if (row < kb) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int jj = quarter * 16 + j;
+            const long long off = (KIND == CS3_LU) ? (long long) row + (long long) (kb + jj) * r
+                                                   : (long long) (kb + jj) + (long long) row * r;
+            acc += load_if(L, off, jj < bw) * y[jj < bw ? jj : 0];
+        }
+    }
+    part[quarter][tid & 63] = acc;
+    __syncthreads();
+    if (tid < 64 && row < kb)
+        v[row] -= ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
+}
+
 // ----------------------------------------------------------- permutations --
 // dst[k, :] = src[q[k], :]  (gather) or dst[q[k], :] = src[k, :] (scatter)
 __global__ void __launch_bounds__(256)
@@ -1153,7 +1346,8 @@ hipError_t prepare_kernels()
     if (e != hipSuccess) return e;
     const void *solve_fns[] = {
         (const void *) k_fwd_blk<CS3_LU>, (const void *) k_fwd_blk<CS3_CHOLESKY>,
-        (const void *) k_bwd_blk<CS3_LU>, (const void *) k_bwd_blk<CS3_CHOLESKY>};
+        (const void *) k_bwd_blk<CS3_LU>, (const void *) k_bwd_blk<CS3_CHOLESKY>,
+        (const void *) k_bwd_big_init<CS3_LU>, (const void *) k_bwd_big_init<CS3_CHOLESKY>};
     for (const void *f : solve_fns) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, big);
         if (e != hipSuccess) return e;
@@ -1269,6 +1463,34 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
                 hipLaunchKernelGGL((k_bwd_wave<KIND, KT>), grid, dim3(256), 0, st, D.sdesc, g.first, g.count, D.st_idx,
                                    D.pool, X, nrhs, D.pool_size, xs);
         }
+    } else if (g.cls == 2) {
+        const unsigned by = (unsigned) (D.batch * nrhs);
+        const int nchunk = (g.max_w + SOLVE_BW - 1) / SOLVE_BW;
+        const int slices = std::max(1, (g.max_r + 63) / 64);
+        if (forward) {
+            // rows that no child updates have no source in the gather list: start from zero
+            hipError_t me = hipMemsetAsync(D.bigv, 0, (size_t) (D.batch * nrhs * D.bv_size) * sizeof(double), st);
+            if (me != hipSuccess) return me;
+            hipLaunchKernelGGL(k_fwd_big_gather, dim3(4, by, g.count), dim3(256), 0, st, D.sdesc, g.first, D.fasm_src,
+                               D.fasm_tgt, D.flong_src, D.cv, X, D.bigv, nrhs, cvs, xs, D.bv_size);
+            CS3_LAUNCH_CHECK();
+            for (int c = 0; c < nchunk; ++c) {
+                hipLaunchKernelGGL((k_fwd_big_step<KIND>), dim3(slices, by, g.count), dim3(256), 0, st, D.sdesc, g.first,
+                                   c * SOLVE_BW, D.pool, D.cv, X, D.bigv, nrhs, D.pool_size, cvs, xs, D.bv_size);
+                CS3_LAUNCH_CHECK();
+            }
+        } else {
+            const size_t lds = (size_t) std::max(1, g.max_r) * sizeof(double);
+            hipLaunchKernelGGL((k_bwd_big_init<KIND>), dim3(2, by, g.count), dim3(256), lds, st, D.sdesc, g.first,
+                               D.st_idx, D.pool, X, D.bigv, nrhs, D.pool_size, xs, D.bv_size);
+            CS3_LAUNCH_CHECK();
+            for (int c = 0; c < nchunk; ++c) {
+                hipLaunchKernelGGL((k_bwd_big_step<KIND>), dim3(slices, by, g.count), dim3(256), 0, st, D.sdesc, g.first,
+                                   c, D.pool, X, D.bigv, nrhs, D.pool_size, xs, D.bv_size);
+                CS3_LAUNCH_CHECK();
+            }
+        }
+        return hipSuccess;
     } else {
         dim3 grid((unsigned) g.count, (unsigned) D.batch, (unsigned) nrhs);
         const size_t lds = (size_t) (g.max_r + 1 + SOLVE_BW) * sizeof(double);

@@ -566,7 +566,13 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
             S.fasm_ptr[s + 1] = (i64) S.fasm_tgt.size();
         }
     }
-    auto solve_kind = [&](i32 s) { return (order_r(s) <= 128 && width(s) <= 64) ? 0 : 1; };
+    auto solve_kind = [&](i32 s) {
+        if (order_r(s) <= 128 && width(s) <= 64) return 0;
+        return (width(s) > 64 && order_r(s) > 136) ? 2 : 1;
+    };
+    S.bv_off.assign(ns, 0); S.bv_size = 0;
+    for (i32 s = 0; s < ns; ++s)
+        if (solve_kind(s) == 2) { S.bv_off[s] = S.bv_size; S.bv_size += order_r(s); }
     S.ssched.resize(ns);
     std::iota(S.ssched.begin(), S.ssched.end(), 0);
     std::stable_sort(S.ssched.begin(), S.ssched.end(), [&](i32 a, i32 b) {

@@ -334,7 +334,7 @@ int cs3_analyze(int64_t kind, int64_t order, int64_t n, const int32_t *Ap, const
     try {
         h = new cs3_handle_s();
         h->batch = batch;
-        analyze((int) kind, (int) order, n, Ap, Ai, q_given, h->S);
+        analyze((int) kind, (int) order, n, Ap, Ai, q_given, h->S, batch);
     } catch (const std::bad_alloc &) {
         delete h; set_error("cs3_analyze: out of memory"); return CS3_ERR_ALLOC;
     } catch (const std::exception &e) {

@@ -43,6 +43,7 @@ struct LaunchGroup {          // fronts of one level that share a kernel configu
 
 struct Symbolic {
     i64 n = 0, nnzA = 0;
+    i64 batch = 1;                            // matrices sharing this analysis (tunes the launch configuration)
     int kind = CS3_LU;
     // ordering (original labels)
     std::vector<i32> q_amd, parent_amd, post_amd, count_amd;
@@ -103,7 +104,7 @@ constexpr i32 ASM_LONG = 0x40000000;          // flag on a target: sources are l
 
 // Full analysis.  order: cs3_order.  Throws std::runtime_error on bad input.
 void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
-             const i32 *q_given, Symbolic &S);
+             const i32 *q_given, Symbolic &S, i64 batch = 1);
 
 // Level schedule of a general triangular CSC matrix (cs3_csc_lsolve/usolve).
 struct TriSchedule {

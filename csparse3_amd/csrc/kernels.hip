@@ -327,10 +327,11 @@ front_wave_body(const FrontDesc &d, int first, double *F,
     const int ld = r | 1;
     // four waves assemble the front (the gather is latency-bound: more loads in flight), one eliminates it
     CS3_STAMP(0);
-    for (int i = threadIdx.x; i < r * ld; i += 256) F[i] = 0.0;
+    const int nwaves = blockDim.x >> 6;
+    for (int i = threadIdx.x; i < r * ld; i += blockDim.x) F[i] = 0.0;
     __syncthreads();
     CS3_STAMP(1);
-    gather_front(d.asm_begin, d.asm_count >> 6, (threadIdx.x >> 6) * GATHER_UNROLL, 4 * GATHER_UNROLL,
+    gather_front(d.asm_begin, d.asm_count >> 6, (threadIdx.x >> 6) * GATHER_UNROLL, nwaves * GATHER_UNROLL,
                  asm_src, asm_tgt, long_src,
                  [&](int q) -> const double * { return (q >= 0) ? pool + q : ax + ~q; },
                  [&](int t, double v) { F[t] = v; });
@@ -419,6 +420,22 @@ front_wave_body(const FrontDesc &d, int first, double *F,
     if (bad) flag_column(status, d.c0 + bad_col);
     CS3_STAMP(5);
 #undef CS3_STAMP
+}
+
+// The one-wave path as its own launch, one wave per front: used when a batch of matrices keeps
+// the chip busy anyway, so the three helper waves of k_front_mix would only cost occupancy.
+template <int KIND>
+__global__ void __launch_bounds__(64)
+k_front_wave(const FrontDesc *__restrict__ fdesc, int first,
+             const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
+             const double *__restrict__ ax_all, double *__restrict__ pool_all,
+             long long nnz_a, long long pool_stride, double inv_tol, int *status, long long *tbuf)
+{
+    extern __shared__ __attribute__((aligned(16))) double F[];
+    const long long t_start = tbuf ? (long long) __builtin_amdgcn_s_memtime() : 0;
+    const FrontDesc d = fdesc[first + blockIdx.x];
+    front_wave_body<KIND, 32>(d, first, F, asm_src, asm_tgt, long_src, ax_all, pool_all, nnz_a, pool_stride,
+                              inv_tol, status, tbuf, t_start);
 }
 
 // Every front of order <= 64 in one launch: one wave eliminates the small ones (r <= 32), the
@@ -1322,7 +1339,8 @@ static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g
 #define CS3_FRONT_ARGS D.fdesc, g.first, D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool, D.nnz_a, D.pool_size, inv_tol, D.status, D.tbuf
     switch (g.cls) {
     case FC_R16:
-    case FC_R32:
+    case FC_R32:      // only present when the analysis split the small fronts off (batched handles)
+        hipLaunchKernelGGL((k_front_wave<KIND>), grid, dim3(64), lds, st, CS3_FRONT_ARGS); break;
     case FC_R64:
         hipLaunchKernelGGL((k_front_mix<KIND>), grid, dim3(256), lds, st, CS3_FRONT_ARGS); break;
     default:

@@ -107,8 +107,9 @@ double seconds_since(std::chrono::steady_clock::time_point t0)
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
-int front_class(i64 r)
+int front_class(i64 r, bool split_small)
 {
+    if (r <= 32 && split_small) return FC_R32;   // batched handles: one wave per front, its own launch
     if (r <= 64) return FC_R64;       // one launch: k_front_mix (one wave for r <= 32, 16 x 16 threads above)
     if (r <= 136) return FC_LDS;      // (136*137 + 4*136 + 6) doubles = 153 KB of the 160 KB LDS
     return FC_BIG;
@@ -117,7 +118,7 @@ int front_class(i64 r)
 }  // namespace
 
 void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
-             const i32 *q_given, Symbolic &S)
+             const i32 *q_given, Symbolic &S, i64 batch)
 {
     if (n < 0 || !Ap || (n > 0 && !Ai && Ap[n] > 0)) throw std::runtime_error("analyze: null input");
     if (kind != CS3_LU && kind != CS3_CHOLESKY) throw std::runtime_error("analyze: unknown kind");
@@ -137,7 +138,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
             }
     }
     S = Symbolic();
-    S.n = n; S.nnzA = nnzA; S.kind = kind;
+    S.n = n; S.nnzA = nnzA; S.kind = kind; S.batch = batch;
 
     // ---- 1. fill-reducing order on the pattern of A + A'
     auto t0 = std::chrono::steady_clock::now();
@@ -377,7 +378,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     S.max_front = 0; S.max_width = 0; S.flops = 0.0;
     for (i32 s = 0; s < ns; ++s) {                   // panels of the LDS-resident fronts
         const i64 w = width(s), r = order_r(s), nb = r - w;
-        S.sn_class[s] = front_class(r);
+        S.sn_class[s] = front_class(r, S.batch >= 8);
         S.cv_off[s] = cvoff; cvoff += nb;
         S.rel_ptr[s + 1] = S.rel_ptr[s] + nb;
         S.max_front = std::max(S.max_front, r);

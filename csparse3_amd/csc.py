@@ -119,3 +119,12 @@ def usolve(U, x):
     """x = U \\ x in place, U an upper-triangular CscMat with the diagonal last in each column."""
     _k.csc_usolve_f(U.n, U.indptr, U.indices, U.data, x)
     return x
+
+
+def pack_4_by_4(A11, A12, A21, A22):
+    """[[A11, A12], [A21, A22]] assembled on the device (csc.py:588-606: the power-flow Jacobian layout)."""
+    m, n, Pi, Pp, Px = _k.csc_stack_4_by_4_ff(A11.m, A11.n, A11.indices, A11.indptr, A11.data,
+                                              A12.m, A12.n, A12.indices, A12.indptr, A12.data,
+                                              A21.m, A21.n, A21.indices, A21.indptr, A21.data,
+                                              A22.m, A22.n, A22.indices, A22.indptr, A22.data)
+    return CscMat(m, n, indptr=Pp, indices=Pi, data=Px)

@@ -85,6 +85,7 @@ def lib():
         L.cs3_csc_lsolve.argtypes = [I64, _i32p, _i32p, _f64p, _f64p, I64]
         L.cs3_csc_usolve.argtypes = [I64, _i32p, _i32p, _f64p, _f64p, I64]
         L.cs3_csc_matvec.argtypes = [I64, I64, _i32p, _i32p, _f64p, _f64p, _f64p, I64]
+        L.cs3_csc_stack_4_by_4.argtypes = [I64, I64, _i32p, _i32p, _f64p] * 4 + [_i32p, _i32p, _f64p]
         _lib = L
     return _lib
 
@@ -346,3 +347,16 @@ def csc_mat_vec_ff(m, n, Ap, Ai, Ax, x):
     y = np.empty((m,) if x.ndim == 1 else (m, k), dtype=np.float64)
     _check(lib().cs3_csc_matvec(m, n, _pi(Ap), _pi(Ai), _pf(Ax), _pf(x), _pf(y), k))
     return y
+
+
+def csc_stack_4_by_4_ff(am, an, Ai, Ap, Ax, bm, bn, Bi, Bp, Bx, cm, cn, Ci, Cp, Cx, dm, dn, Di, Dp, Dx):
+    """[[A, B], [C, D]] on the device; argument and return order (m, n, indices, indptr, data) as the
+    reference's csc_stack_4_by_4_ff (csc_numba.py:640-720)."""
+    assert am == bm and cm == dm and an == cn and bn == dn          # csc_numba.py:679-682
+    a = [_i32(Ai), _i32(Ap), _f64(Ax), _i32(Bi), _i32(Bp), _f64(Bx), _i32(Ci), _i32(Cp), _f64(Cx), _i32(Di), _i32(Dp), _f64(Dx)]
+    nnz = int(a[1][an]) + int(a[4][bn]) + int(a[7][cn]) + int(a[10][dn])
+    Pi = np.empty(nnz, dtype=np.int32); Pp = np.empty(an + bn + 1, dtype=np.int32); Px = np.empty(nnz, dtype=np.float64)
+    _check(lib().cs3_csc_stack_4_by_4(am, an, _pi(a[0]), _pi(a[1]), _pf(a[2]), bm, bn, _pi(a[3]), _pi(a[4]), _pf(a[5]),
+                                      cm, cn, _pi(a[6]), _pi(a[7]), _pf(a[8]), dm, dn, _pi(a[9]), _pi(a[10]), _pf(a[11]),
+                                      _pi(Pi), _pi(Pp), _pf(Px)))
+    return am + cm, an + bn, Pi, Pp, Px

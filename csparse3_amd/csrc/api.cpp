@@ -77,18 +77,6 @@ int ensure_device(cs3_handle h)
     D.kind = S.kind; D.n = S.n; D.nnz_a = S.nnzA; D.batch = h->batch;
     D.vals_size = S.vals_size; D.pool_size = S.pool_size; D.cv_size = S.cv_size; D.big_begin = S.big_begin;
     D.bv_size = S.bv_size;
-    std::vector<FrontMeta> meta(S.nsuper);
-    for (i32 s = 0; s < S.nsuper; ++s) {
-        FrontMeta &m = meta[s];
-        m.lpan = S.lpan_off[s]; m.upan = S.upan_off[s]; m.cv = S.cv_off[s];
-        m.rel = S.rel_ptr[s]; m.st = S.st_ptr[s];
-        m.c0 = S.sn_ptr[s];
-        m.r = (int) (S.st_ptr[s + 1] - S.st_ptr[s]);
-        m.w = S.sn_ptr[s + 1] - S.sn_ptr[s];
-        m.u_sk = S.u_sk[s]; m.u_sj = S.u_sj[s];
-        m.child_begin = S.child_ptr[s]; m.child_end = S.child_ptr[s + 1];
-        m.parent = S.sn_parent[s];
-    }
     std::vector<FrontDesc> fdesc(S.nsuper);
     i64 dbuf_size = 0;
     for (i32 t = 0; t < S.nsuper; ++t) {
@@ -123,11 +111,7 @@ int ensure_device(cs3_handle h)
     if ((rc = upload(&D.fasm_src, S.fasm_src))) return rc;
     if ((rc = upload(&D.fasm_tgt, S.fasm_tgt))) return rc;
     if ((rc = upload(&D.flong_src, S.flong_src))) return rc;
-    if ((rc = upload(&D.meta, meta))) return rc;
     if ((rc = upload(&D.fdesc, fdesc))) return rc;
-    if ((rc = upload(&D.sched, S.sched))) return rc;
-    if ((rc = upload(&D.child_idx, S.child_idx))) return rc;
-    if ((rc = upload(&D.rel_idx, S.rel_idx))) return rc;
     if ((rc = upload(&D.st_idx, S.st_idx))) return rc;
     if ((rc = upload(&D.asm_src, S.asm_src))) return rc;
     if ((rc = upload(&D.asm_tgt, S.asm_tgt))) return rc;
@@ -354,7 +338,7 @@ int cs3_free(cs3_handle h)
         drop_solve_graphs(h);
         if (h->cap_stream) (void) hipStreamDestroy(h->cap_stream);
         h->fj.destroy();
-        void *ptrs[] = {D.meta, D.fdesc, D.sched, D.child_idx, D.rel_idx, D.st_idx, D.asm_src, D.asm_tgt, D.long_src,
+        void *ptrs[] = {D.fdesc, D.st_idx, D.asm_src, D.asm_tgt, D.long_src,
                         D.sdesc, D.fasm_src, D.fasm_tgt, D.flong_src, D.q, D.ax, D.pool, D.dbuf, D.tbuf, D.bigv, D.cv, D.xp, D.status, h->d_lmap, h->d_umap, h->d_lx, h->d_ux};
         for (void *p : ptrs) if (p) (void) hipFree(p);
     }
@@ -638,6 +622,54 @@ int cs3_csc_matvec(int64_t m, int64_t n, const int32_t *Ap, const int32_t *Ai, c
     if (e == hipSuccess) e = hipMemcpy(d_x, X, (size_t) (n * k) * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = launch_matvec_rows(d_rp, d_rj, d_rx, d_x, d_y, m, (int) k, nullptr);
     if (e == hipSuccess) e = hipMemcpy(Y, d_y, (size_t) (m * k) * sizeof(double), hipMemcpyDeviceToHost);
+    cleanup();
+    CS3_HIP(e);
+    return CS3_OK;
+}
+
+int cs3_csc_stack_4_by_4(int64_t am, int64_t an, const int32_t *Ai, const int32_t *Ap, const double *Ax,
+                         int64_t bm, int64_t bn, const int32_t *Bi, const int32_t *Bp, const double *Bx,
+                         int64_t cm, int64_t cn, const int32_t *Ci, const int32_t *Cp, const double *Cx,
+                         int64_t dm, int64_t dn, const int32_t *Di, const int32_t *Dp, const double *Dx,
+                         int32_t *Pi, int32_t *Pp, double *Px)
+{
+    // the reference asserts these (csc_numba.py:679-682)
+    if (am != bm || cm != dm || an != cn || bn != dn) { set_error("cs3_csc_stack_4_by_4: incompatible block shapes"); return CS3_ERR_ARG; }
+    if (!Ap || !Bp || !Cp || !Dp || !Pp) { set_error("cs3_csc_stack_4_by_4: null argument"); return CS3_ERR_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device visible: cs3_csc_stack_4_by_4 runs on the GPU only"); return CS3_ERR_HIP;
+    }
+    const i64 nnz = (i64) Ap[an] + Bp[bn] + Cp[cn] + Dp[dn];
+    struct Blk { const int32_t *p, *i; const double *x; i64 n; int *dp = nullptr, *di = nullptr; double *dx = nullptr; };
+    Blk blk[4] = {{Ap, Ai, Ax, an}, {Bp, Bi, Bx, bn}, {Cp, Ci, Cx, cn}, {Dp, Di, Dx, dn}};
+    int *d_pp = nullptr, *d_pi = nullptr; double *d_px = nullptr;
+    auto cleanup = [&]() {
+        for (Blk &b : blk) { if (b.dp) (void) hipFree(b.dp); if (b.di) (void) hipFree(b.di); if (b.dx) (void) hipFree(b.dx); }
+        if (d_pp) (void) hipFree(d_pp); if (d_pi) (void) hipFree(d_pi); if (d_px) (void) hipFree(d_px);
+    };
+    hipError_t e = hipSuccess;
+    for (Blk &b : blk) {
+        const size_t bn_ = (size_t) b.p[b.n];
+        if (e == hipSuccess) e = hipMalloc((void **) &b.dp, (size_t) (b.n + 1) * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **) &b.di, std::max<size_t>(1, bn_) * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **) &b.dx, std::max<size_t>(1, bn_) * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpy(b.dp, b.p, (size_t) (b.n + 1) * sizeof(int), hipMemcpyHostToDevice);
+        if (e == hipSuccess && bn_) e = hipMemcpy(b.di, b.i, bn_ * sizeof(int), hipMemcpyHostToDevice);
+        if (e == hipSuccess && bn_) e = hipMemcpy(b.dx, b.x, bn_ * sizeof(double), hipMemcpyHostToDevice);
+    }
+    const i64 ncol = an + bn;
+    if (e == hipSuccess) e = hipMalloc((void **) &d_pp, (size_t) (ncol + 1) * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **) &d_pi, std::max<size_t>(1, (size_t) nnz) * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **) &d_px, std::max<size_t>(1, (size_t) nnz) * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(d_pp, 0, (size_t) (ncol + 1) * sizeof(int));
+    if (e == hipSuccess)
+        e = launch_stack_4_by_4((int) an, (int) bn, (int) am, (int) bm, blk[0].dp, blk[0].di, blk[0].dx, blk[1].dp, blk[1].di,
+                                blk[1].dx, blk[2].dp, blk[2].di, blk[2].dx, blk[3].dp, blk[3].di, blk[3].dx, d_pp, d_pi, d_px,
+                                nullptr);
+    if (e == hipSuccess) e = hipMemcpy(Pp, d_pp, (size_t) (ncol + 1) * sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && nnz) e = hipMemcpy(Pi, d_pi, (size_t) nnz * sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && nnz) e = hipMemcpy(Px, d_px, (size_t) nnz * sizeof(double), hipMemcpyDeviceToHost);
     cleanup();
     CS3_HIP(e);
     return CS3_OK;

@@ -8,18 +8,7 @@
 
 namespace cs3 {
 
-// One front (supernode), indexed by supernode id: what the solve kernels read.
-// Offsets are element offsets into the per-matrix pool / cv pool and into the
-// rel_idx / st_idx index arrays.
-struct FrontMeta {
-    long long lpan, upan, cv, rel, st;
-    int c0, r, w;
-    int u_sk, u_sj;               // U(k, j) = pool[upan + k*u_sk + (j-w)*u_sj]
-    int child_begin, child_end;   // range in child_idx
-    int parent;                   // -1 for a root
-};
-
-// The same front as the factorisation kernels see it, stored in SCHEDULE order
+// One front (supernode) as the factorisation kernels see it, stored in SCHEDULE order
 // so that block b of a launch group reads entry first + b with no indirection.
 struct FrontDesc {
     long long lpan, upan, cb;     // pool offsets: L panel (ld r), U panel, contribution block
@@ -47,9 +36,8 @@ struct DeviceFactor {
     long long n = 0, nnz_a = 0, batch = 1;
     long long vals_size = 0, pool_size = 0, cv_size = 0;
     long long big_begin = 0;      // big-front buffers: pool[big_begin, vals_size), zeroed per factorisation
-    FrontMeta *meta = nullptr;
     FrontDesc *fdesc = nullptr;
-    int *sched = nullptr, *child_idx = nullptr, *rel_idx = nullptr, *st_idx = nullptr;
+    int *st_idx = nullptr;        // row structures (backward sweep: rows of the ancestors)
     int *asm_src = nullptr, *asm_tgt = nullptr, *long_src = nullptr;
     SolveDesc *sdesc = nullptr;
     int *fasm_src = nullptr, *fasm_tgt = nullptr, *flong_src = nullptr;
@@ -91,6 +79,10 @@ hipError_t launch_extract(const double *vals, const long long *map, double *out,
                           hipStream_t st);
 hipError_t launch_tri_level(const int *rows, int nrows, const int *Rp, const int *Rj, const long long *Rmap,
                             const long long *diag, const double *Gx, double *X, int nrhs, hipStream_t st);
+hipError_t launch_stack_4_by_4(int an, int bn, int am, int bm, const int *Ap, const int *Ai, const double *Ax,
+                               const int *Bp, const int *Bi, const double *Bx, const int *Cp, const int *Ci,
+                               const double *Cx, const int *Dp, const int *Di, const double *Dx,
+                               int *Pp, int *Pi, double *Px, hipStream_t st);
 hipError_t launch_matvec_rows(const int *Rp, const int *Rj, const double *Rx, const double *X, double *Y,
                               long long m, int nrhs, hipStream_t st);
 

@@ -1297,6 +1297,51 @@ k_matvec_rows(const int *__restrict__ Rp, const int *__restrict__ Rj,
     }
 }
 
+// 2 x 2 block stacking [[A, B], [C, D]] in CSC (power-flow Jacobian assembly), the layout of
+// csc_stack_4_by_4_ff (csc_numba.py:640-720): output column j < an is A(:,j) followed by C(:,j)
+// with rows shifted by am; column an + j is B(:,j) followed by D(:,j) shifted by bm.  Column
+// pointers are closed-form sums of the inputs' pointers, so no scan is needed.  One wave per column.
+__global__ void __launch_bounds__(256)
+k_stack_4_by_4(int an, int bn, int am, int bm,
+               const int *__restrict__ Ap, const int *__restrict__ Ai, const double *__restrict__ Ax,
+               const int *__restrict__ Bp, const int *__restrict__ Bi, const double *__restrict__ Bx,
+               const int *__restrict__ Cp, const int *__restrict__ Ci, const double *__restrict__ Cx,
+               const int *__restrict__ Dp, const int *__restrict__ Di, const double *__restrict__ Dx,
+               int *__restrict__ Pp, int *__restrict__ Pi, double *__restrict__ Px)
+{
+    const int col = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (col >= an + bn) return;
+    const bool left = col < an;
+    const int j = left ? col : col - an;
+    const int *Tp = left ? Ap : Bp, *Ti = left ? Ai : Bi;
+    const int *Bp2 = left ? Cp : Dp, *Bi2 = left ? Ci : Di;
+    const double *Tx = left ? Ax : Bx, *Bx2 = left ? Cx : Dx;
+    const int shift = left ? am : bm;
+    const int base = left ? 0 : Ap[an] + Cp[an];
+    const int out0 = base + Tp[j] + Bp2[j];
+    const int n1 = Tp[j + 1] - Tp[j], n2 = Bp2[j + 1] - Bp2[j];
+    for (int k = lane; k < n1; k += 64) { Pi[out0 + k] = Ti[Tp[j] + k]; Px[out0 + k] = Tx[Tp[j] + k]; }
+    for (int k = lane; k < n2; k += 64) { Pi[out0 + n1 + k] = Bi2[Bp2[j] + k] + shift; Px[out0 + n1 + k] = Bx2[Bp2[j] + k]; }
+    if (lane == 0) {
+        Pp[col + 1] = out0 + n1 + n2;
+        if (col == 0) Pp[0] = 0;
+    }
+}
+
+hipError_t launch_stack_4_by_4(int an, int bn, int am, int bm, const int *Ap, const int *Ai, const double *Ax,
+                               const int *Bp, const int *Bi, const double *Bx, const int *Cp, const int *Ci,
+                               const double *Cx, const int *Dp, const int *Di, const double *Dx,
+                               int *Pp, int *Pi, double *Px, hipStream_t st)
+{
+    const int ncol = an + bn;
+    if (ncol == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_stack_4_by_4, dim3((ncol + 3) / 4), dim3(256), 0, st, an, bn, am, bm, Ap, Ai, Ax, Bp, Bi, Bx,
+                       Cp, Ci, Cx, Dp, Di, Dx, Pp, Pi, Px);
+    hipError_t e = hipGetLastError();
+    return e;
+}
+
 // ================================================================ launchers ==
 #define CS3_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 

@@ -163,6 +163,16 @@ int cs3_csc_usolve(int64_t n, const int32_t *Up, const int32_t *Ui, const double
 int cs3_csc_matvec(int64_t m, int64_t n, const int32_t *Ap, const int32_t *Ai,
                    const double *Ax, const double *X, double *Y, int64_t k);
 
+/* [[A, B], [C, D]] in CSC on the device: csc_stack_4_by_4_ff / pack_4_by_4 (csc_numba.py:640-720,
+ * csc.py:588-606), the power-flow Jacobian assembly.  Argument order (m, n, indices, indptr, data)
+ * as in the reference; outputs Pi[nnz], Pp[an+bn+1], Px[nnz] with nnz = the four blocks' nnz,
+ * caller-allocated.  Incompatible block shapes (the reference asserts) give CS3_ERR_ARG. */
+int cs3_csc_stack_4_by_4(int64_t am, int64_t an, const int32_t *Ai, const int32_t *Ap, const double *Ax,
+                         int64_t bm, int64_t bn, const int32_t *Bi, const int32_t *Bp, const double *Bx,
+                         int64_t cm, int64_t cn, const int32_t *Ci, const int32_t *Cp, const double *Cx,
+                         int64_t dm, int64_t dn, const int32_t *Di, const int32_t *Dp, const double *Dx,
+                         int32_t *Pi, int32_t *Pp, double *Px);
+
 #ifdef __cplusplus
 }
 #endif

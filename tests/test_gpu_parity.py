@@ -346,3 +346,28 @@ def test_call_order_and_argument_errors(gpu):
             F.solve(np.ones(n + 1))                          # wrong length
         x = F.solve(np.ones((n, 3)))
         assert x.shape == (n, 3)
+
+
+def test_jacobian_block_stacking_matches_the_reference_kernel(gpu):
+    """csc_stack_4_by_4_ff on the device against the reference's own output (first row)."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "substrate.npz"))
+    g = lambda k: G["st_" + k]
+    am, an, bn, cm = int(g("am")), int(g("an")), int(g("bn")), int(g("cm"))
+    m, n, Pi, Pp, Px = gpu.csc_stack_4_by_4_ff(am, an, g("Ai"), g("Ap"), g("Ax"), am, bn, g("Bi"), g("Bp"), g("Bx"),
+                                               cm, an, g("Ci"), g("Cp"), g("Cx"), cm, bn, g("Di"), g("Dp"), g("Dx"))
+    assert (m, n) == (int(g("m")), int(g("n")))
+    assert np.array_equal(Pi, g("i")) and np.array_equal(Pp, g("p")) and np.array_equal(Px, g("x"))
+    with pytest.raises(AssertionError):
+        gpu.csc_stack_4_by_4_ff(am + 1, an, g("Ai"), g("Ap"), g("Ax"), am, bn, g("Bi"), g("Bp"), g("Bx"),
+                                cm, an, g("Ci"), g("Cp"), g("Cx"), cm, bn, g("Di"), g("Dp"), g("Dx"))
+    # and through the class: pack_4_by_4 then factor + solve the assembled Jacobian
+    from csparse3_amd.csc import CscMat, pack_4_by_4
+    m0, n0, Ap, Ai, Ax = synth.jacobian_like()
+    A = CscMat(m0, n0, indptr=Ap, indices=Ai, data=Ax)
+    Z = CscMat(m0, n0, indptr=np.zeros(n0 + 1, dtype=np.int32), indices=np.zeros(0, dtype=np.int32), data=np.zeros(0))
+    J = pack_4_by_4(A, Z, Z, A)                      # block diagonal of two Jacobians
+    b = np.random.default_rng(0).standard_normal(2 * n0)
+    x = J.solve(b, tol=1e-3)
+    A0 = csc_to_scipy(m0, n0, Ap, Ai, Ax)
+    assert np.abs(A0 @ x[:n0] - b[:n0]).max() < 1e-11 and np.abs(A0 @ x[n0:] - b[n0:]).max() < 1e-11

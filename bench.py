@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--n", type=int, default=50000)
     ap.add_argument("--rhs", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse N > 1 on one GPU)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -85,10 +87,15 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     # ---- synthetic workload: same pattern on every rank, values differ per rank
     m, n, Ap, Ai, Ax = synth.grid_jacobian(n=args.n, seed=args.n)
@@ -144,7 +151,7 @@ def main():
     t_solve_ms = float(np.mean([ev[3 * s + 1].elapsed_time(ev[3 * s + 2]) for s in range(args.steps)]))
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

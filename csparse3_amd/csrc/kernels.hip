@@ -695,41 +695,42 @@ k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__res
         }
         return;
     }
+    // right-looking triangular solves: once x_c is known it is applied to every later column, so the
+    // FMAs of one step are independent of each other (no 32-deep dependent chain per row)
     if (bi > 0) {
         if (tid < 64 && tid < nrow) {              // x U_D = t  (Cholesky: x L_D' = t), one row per lane
-            double x[BIG_NB];
+            double t[BIG_NB];
+#pragma unroll
+            for (int c = 0; c < BIG_NB; ++c) t[c] = T[tid][c];
 #pragma unroll
             for (int c = 0; c < BIG_NB; ++c) {
                 if (c < bw) {
-                    double v = T[tid][c];
+                    const double x = t[c] / D[c][c];
+                    if (KIND == CS3_LU && !(fabs(x) <= inv_tol)) flag_column(status, d.c0 + kb + c);
+                    F[(row0 + tid) + (long long) (kb + c) * ld] = x;
 #pragma unroll
-                    for (int k = 0; k < c; ++k) v -= x[k] * ((KIND == CS3_LU) ? D[k][c] : D[c][k]);
-                    x[c] = v / D[c][c];
-                    if (KIND == CS3_LU && !(fabs(x[c]) <= inv_tol)) flag_column(status, d.c0 + kb + c);
-                    F[(row0 + tid) + (long long) (kb + c) * ld] = x[c];
-                } else {
-                    x[c] = 0.0;
+                    for (int j = c + 1; j < BIG_NB; ++j) t[j] -= x * ((KIND == CS3_LU) ? D[c][j] : D[j][c]);
                 }
             }
         }
     } else {
         if (tid < 64 && tid < ncol) {              // L_D u = t, L_D unit lower, one column per lane
-            double u[BIG_NB];
+            double t[BIG_NB];
+#pragma unroll
+            for (int c = 0; c < BIG_NB; ++c) t[c] = T[tid][c];
 #pragma unroll
             for (int c = 0; c < BIG_NB; ++c) {
                 if (c < bw) {
-                    double v = T[tid][c];
+                    const double u = t[c];
+                    F[(kb + c) + (long long) (col0 + tid) * ld] = u;
 #pragma unroll
-                    for (int k = 0; k < c; ++k) v -= D[c][k] * u[k];
-                    u[c] = v;
-                    F[(kb + c) + (long long) (col0 + tid) * ld] = v;
-                } else {
-                    u[c] = 0.0;
+                    for (int j = c + 1; j < BIG_NB; ++j) t[j] -= D[j][c] * u;
                 }
             }
         }
     }
 }
+
 
 // ------------------------------------------------------ supernodal solves --
 // X is [n, nrhs] row-major in pivot order; blockIdx.z = right-hand side,

@@ -71,6 +71,7 @@ def lib():
         L.cs3_factor.argtypes = [vp, _f64p, C.c_double]
         L.cs3_factor_dev.argtypes = [vp, vp, C.c_double, vp]
         L.cs3_factor_status.argtypes = [vp, vp]
+        L.cs3_factor_solve_dev.argtypes = [vp, vp, C.c_double, vp, I64, vp]
         for f in (L.cs3_solve, L.cs3_lsolve, L.cs3_usolve):
             f.argtypes = [vp, _f64p, I64]
         for f in (L.cs3_solve_dev, L.cs3_lsolve_dev, L.cs3_usolve_dev):
@@ -247,6 +248,10 @@ class Factorization:
     # -- numeric, device pointers (e.g. torch.Tensor.data_ptr()) on a HIP stream
     def factor_dev(self, ax_ptr, tol=0.0, stream=0):
         _check(lib().cs3_factor_dev(self._h, C.c_void_p(ax_ptr), tol, C.c_void_p(stream)))
+
+    def factor_solve_dev(self, ax_ptr, x_ptr, k=1, tol=0.0, stream=0):
+        """(Re)factorise and solve in one call (cs_lusol on resident data); X is overwritten."""
+        _check(lib().cs3_factor_solve_dev(self._h, C.c_void_p(ax_ptr), tol, C.c_void_p(x_ptr), k, C.c_void_p(stream)))
 
     def factor_status(self, stream=0):
         _check(lib().cs3_factor_status(self._h, C.c_void_p(stream)))

@@ -41,6 +41,8 @@ struct cs3_handle_s {
     hipGraphExec_t factor_graph = nullptr;
     double factor_graph_inv_tol = 0.0;
     std::map<int, hipGraphExec_t> solve_graphs;   // keyed by nrhs
+    std::map<int, hipGraphExec_t> fused_graphs;   // factor + overlapped forward + backward, keyed by nrhs
+    double fused_inv_tol = 0.0;
     i64 *d_lmap = nullptr, *d_umap = nullptr;
     double *d_lx = nullptr, *d_ux = nullptr;
     long long fail_col = -1;
@@ -61,6 +63,8 @@ void drop_solve_graphs(cs3_handle h)
 {
     for (auto &kv : h->solve_graphs) (void) hipGraphExecDestroy(kv.second);
     h->solve_graphs.clear();
+    for (auto &kv : h->fused_graphs) (void) hipGraphExecDestroy(kv.second);
+    h->fused_graphs.clear();
 }
 
 int ensure_device(cs3_handle h)
@@ -247,6 +251,46 @@ int run_solve(cs3_handle h, double *x_dev, long long k, int mode, hipStream_t st
     return CS3_OK;
 }
 
+// numeric factorisation and full solve in one graph; the forward sweep runs beside the factorisation
+int run_factor_solve(cs3_handle h, const double *ax_dev, double *x_dev, long long k, double tol, hipStream_t st)
+{
+    if (k < 1 || k > INT_MAX) { set_error("factor_solve: bad number of right-hand sides"); return CS3_ERR_ARG; }
+    int rc = ensure_rhs_capacity(h, k);
+    if (rc) return rc;
+    DeviceFactor &D = h->D;
+    const int nrhs = (int) k;
+    const double inv_tol = (tol > 0.0) ? 1.0 / tol : HUGE_VAL;
+    CS3_HIP(hipMemsetAsync(D.status, 0x7f, sizeof(int), st));
+    if (ax_dev != D.ax && D.nnz_a > 0)
+        CS3_HIP(hipMemcpyAsync(D.ax, ax_dev, (size_t) (D.batch * D.nnz_a) * sizeof(double), hipMemcpyDeviceToDevice, st));
+    CS3_HIP(launch_permute(D, x_dev, D.xp, nrhs, false, st));
+    if (h->use_graph) {
+        if (h->fused_inv_tol != inv_tol) {
+            for (auto &kv : h->fused_graphs) (void) hipGraphExecDestroy(kv.second);
+            h->fused_graphs.clear();
+            h->fused_inv_tol = inv_tol;
+        }
+        auto it = h->fused_graphs.find(nrhs);
+        if (it == h->fused_graphs.end()) {
+            hipGraphExec_t exec = nullptr;
+            rc = capture(h, &exec, [&](hipStream_t cs) {
+                hipError_t e = launch_factor_with_forward(D, h->S.groups, h->S.sgroups, inv_tol, D.xp, nrhs, cs, h->fj);
+                if (e != hipSuccess) return e;
+                return launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, false, cs, h->fj);
+            });
+            if (rc) return rc;
+            it = h->fused_graphs.emplace(nrhs, exec).first;
+        }
+        CS3_HIP(hipGraphLaunch(it->second, st));
+    } else {
+        CS3_HIP(launch_factor_with_forward(D, h->S.groups, h->S.sgroups, inv_tol, D.xp, nrhs, st, h->fj));
+        CS3_HIP(launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, false, st, h->fj));
+    }
+    CS3_HIP(launch_permute(D, D.xp, x_dev, nrhs, true, st));
+    h->factored = true;
+    return CS3_OK;
+}
+
 int guard(cs3_handle h)
 {
     if (!h) { set_error("null handle"); return CS3_ERR_ARG; }
@@ -396,6 +440,14 @@ int cs3_factor_dev(cs3_handle h, const double *Ax_dev, double tol, void *stream)
     if (!Ax_dev && h->S.nnzA > 0) { set_error("cs3_factor_dev: null values"); return CS3_ERR_ARG; }
     if ((rc = ensure_device(h))) return rc;
     return run_factor(h, Ax_dev, tol, (hipStream_t) stream);
+}
+
+int cs3_factor_solve_dev(cs3_handle h, const double *Ax_dev, double tol, double *X_dev, int64_t k, void *stream)
+{
+    int rc = guard(h); if (rc) return rc;
+    if ((!Ax_dev && h->S.nnzA > 0) || !X_dev) { set_error("cs3_factor_solve_dev: null argument"); return CS3_ERR_ARG; }
+    if ((rc = ensure_device(h))) return rc;
+    return run_factor_solve(h, Ax_dev, X_dev, k, tol, (hipStream_t) stream);
 }
 
 int cs3_factor_status(cs3_handle h, void *stream)

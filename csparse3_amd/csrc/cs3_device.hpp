@@ -60,6 +60,7 @@ struct DeviceFactor {
 struct ForkJoin {
     static constexpr int NSIDE = 3;
     hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr};
+    hipStream_t aux = nullptr;             // carries the forward sweep next to the factorisation
     std::vector<hipEvent_t> events;
     size_t next = 0;
     hipError_t init();
@@ -73,6 +74,11 @@ hipError_t launch_factor_levels(const DeviceFactor &D, const std::vector<LaunchG
                                 double inv_tol, hipStream_t st, ForkJoin &fj);
 hipError_t launch_solve_levels(const DeviceFactor &D, const std::vector<LaunchGroup> &groups,
                                double *X, int nrhs, bool forward, hipStream_t st, ForkJoin &fj);
+// Factorisation with the forward sweep partly hidden behind it: the sweep of the finished levels
+// runs on fj.aux beside the factorisation of the tail of the tree (one fork, one join).
+hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<LaunchGroup> &fgroups,
+                                      const std::vector<LaunchGroup> &sgroups, double inv_tol, double *X, int nrhs,
+                                      hipStream_t st, ForkJoin &fj);
 hipError_t launch_permute(const DeviceFactor &D, const double *src, double *dst, int nrhs, bool scatter,
                           hipStream_t st);
 hipError_t launch_extract(const double *vals, const long long *map, double *out, long long count,

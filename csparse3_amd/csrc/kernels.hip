@@ -1425,12 +1425,13 @@ hipError_t ForkJoin::init()
         hipError_t e = hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking);
         if (e != hipSuccess) return e;
     }
-    return hipSuccess;
+    return hipStreamCreateWithFlags(&aux, hipStreamNonBlocking);
 }
 
 void ForkJoin::destroy()
 {
     for (int i = 0; i < NSIDE; ++i) if (side[i]) (void) hipStreamDestroy(side[i]);
+    if (aux) (void) hipStreamDestroy(aux);
     for (hipEvent_t e : events) (void) hipEventDestroy(e);
     events.clear();
 }
@@ -1597,6 +1598,77 @@ hipError_t launch_solve_levels(const DeviceFactor &D, const std::vector<LaunchGr
         }
     }
     return hipSuccess;
+}
+
+// Rough cost of a launch group in dependent-launch units, to place the fork below.
+static int factor_group_cost(const LaunchGroup &g)
+{
+    return (g.cls == FC_BIG) ? 4 * ((g.max_w + BIG_NB - 1) / BIG_NB + 2) : 2;
+}
+static int sweep_group_cost(const LaunchGroup &g)
+{
+    return (g.cls == 2) ? 2 + (g.max_w + SOLVE_BW - 1) / SOLVE_BW : 1;
+}
+
+// Factorisation with the forward sweep partly hidden behind it.  The sweep of levels 0..K needs only
+// the panels of those levels, so once level K is factorised it runs on fj.aux beside the
+// factorisation of levels K+1.. (the tail of the tree: few, large fronts, many dependent launches).
+// K is the last level whose tail is still long enough to cover the sweep; one fork, one join -- a
+// fork per level costs more than it hides (measured).  Same kernels, same operands: same bits.
+hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<LaunchGroup> &fgroups,
+                                      const std::vector<LaunchGroup> &sgroups, double inv_tol, double *X, int nrhs,
+                                      hipStream_t st, ForkJoin &fj)
+{
+    fj.rewind();
+    hipError_t e;
+    if (D.vals_size > D.big_begin) {
+        e = hipMemset2DAsync(D.pool + D.big_begin, (size_t) D.pool_size * sizeof(double), 0,
+                             (size_t) (D.vals_size - D.big_begin) * sizeof(double), (size_t) D.batch, st);
+        if (e != hipSuccess) return e;
+    }
+    const int nlevels = fgroups.empty() ? 0 : fgroups.back().level + 1;
+    std::vector<long long> tail(nlevels + 1, 0), head(nlevels + 1, 0);   // factor cost of levels >= l; sweep cost of levels < l
+    for (const LaunchGroup &g : fgroups) tail[g.level] += factor_group_cost(g);
+    for (int l = nlevels - 1; l >= 0; --l) tail[l] += tail[l + 1];
+    for (const LaunchGroup &g : sgroups) head[g.level + 1] += sweep_group_cost(g);
+    for (int l = 0; l < nlevels; ++l) head[l + 1] += head[l];
+    int fork_level = -1;
+    static const bool overlap = !(getenv("CS3_NO_OVERLAP") && getenv("CS3_NO_OVERLAP")[0] == '1');
+    for (int l = 0; overlap && l + 1 < nlevels; ++l)
+        if (tail[l + 1] >= head[l + 1]) fork_level = l;
+
+    auto sweep = [&](int lo, int hi, hipStream_t s) -> hipError_t {      // forward sweep of levels lo..hi
+        for (const LaunchGroup &g : sgroups) {
+            if (g.level < lo || g.level > hi) continue;
+            hipError_t se = (D.kind == CS3_LU) ? launch_solve_group<CS3_LU>(D, g, X, nrhs, true, s)
+                                               : launch_solve_group<CS3_CHOLESKY>(D, g, X, nrhs, true, s);
+            if (se != hipSuccess) return se;
+        }
+        return hipSuccess;
+    };
+    hipEvent_t swept = nullptr;
+    for (size_t f0 = 0; f0 < fgroups.size(); ) {
+        const int level = fgroups[f0].level;
+        size_t f1 = f0;
+        while (f1 < fgroups.size() && fgroups[f1].level == level) ++f1;
+        e = run_level(fgroups, f0, f1, st, fj, true, [&](const LaunchGroup &g, hipStream_t s) {
+            return (D.kind == CS3_LU) ? launch_front_group<CS3_LU>(D, g, inv_tol, s)
+                                      : launch_front_group<CS3_CHOLESKY>(D, g, inv_tol, s);
+        });
+        if (e != hipSuccess) return e;
+        if (level == fork_level) {
+            hipEvent_t ready;                      // panels of levels 0..fork_level are final
+            if ((e = fj.event(&ready)) != hipSuccess) return e;
+            if ((e = hipEventRecord(ready, st)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(fj.aux, ready, 0)) != hipSuccess) return e;
+            if ((e = sweep(0, fork_level, fj.aux)) != hipSuccess) return e;
+            if ((e = fj.event(&swept)) != hipSuccess) return e;
+            if ((e = hipEventRecord(swept, fj.aux)) != hipSuccess) return e;
+        }
+        f0 = f1;
+    }
+    if (swept && (e = hipStreamWaitEvent(st, swept, 0)) != hipSuccess) return e;
+    return sweep(fork_level + 1, nlevels, st);
 }
 
 hipError_t launch_permute(const DeviceFactor &D, const double *src, double *dst, int nrhs, bool scatter,

@@ -66,6 +66,14 @@ class HipBackend:
         self.F.solve_dev(B.data_ptr(), k, self.stream())
         return B
 
+    def factor_solve(self, Ax, B, tol=0.0):
+        """Factorise and solve in one call (cs3_factor_solve_dev: the forward sweep is partly hidden
+        behind the factorisation); B as in solve()."""
+        ax = torch.as_tensor(np.ascontiguousarray(Ax), dtype=torch.float64).to(self.device)
+        self.F.factor_solve_dev(ax.data_ptr(), B.data_ptr(), B.shape[-1], tol, self.stream())
+        self.F.factor_status(self.stream())
+        return B
+
     def to_device(self, a):
         return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).to(self.device)
 
@@ -128,8 +136,12 @@ def solve_many_matrices(make_backend, AX, B, tol=0.0, group=None, root=0):
     be = None
     if hi > lo:
         be = make_backend(hi - lo)
-        be.factor(AX[lo:hi], tol)
-        X = be.solve(be.to_device(B[lo:hi]).contiguous())
+        Bd = be.to_device(B[lo:hi]).contiguous()
+        if hasattr(be, "factor_solve"):
+            X = be.factor_solve(AX[lo:hi], Bd, tol)
+        else:
+            be.factor(AX[lo:hi], tol)
+            X = be.solve(Bd)
     if world == 1:
         return X
     shapes = [(shard_range(nmat, world, r)[1] - shard_range(nmat, world, r)[0],) + tuple(B.shape[1:])

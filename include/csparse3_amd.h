@@ -106,7 +106,12 @@ int cs3_get_supernodes(cs3_handle h, int32_t *sn_ptr, int32_t *sn_parent, int32_
  * (there is no CPU fallback).  tol <= 0 disables the test. */
 int cs3_factor(cs3_handle h, const double *Ax, double tol);
 int cs3_factor_dev(cs3_handle h, const double *Ax_dev, double tol, void *stream);
-/* Deferred status of the last cs3_factor_dev (synchronises the stream). */
+/* cs_lusol / cs_cholsol as one call on resident data: numeric (re)factorisation of Ax AND the full
+ * solve of X [batch][n, k] in place.  Same results as cs3_factor_dev followed by cs3_solve_dev, bit
+ * for bit; the forward sweep of a tree level runs beside the factorisation of the next level, so
+ * the call is shorter than the two in sequence.  Status via cs3_factor_status. */
+int cs3_factor_solve_dev(cs3_handle h, const double *Ax_dev, double tol, double *X_dev, int64_t k, void *stream);
+/* Deferred status of the last cs3_factor_dev / cs3_factor_solve_dev (synchronises the stream). */
 int cs3_factor_status(cs3_handle h, void *stream);
 
 /* ---- solves (cs_lsolve / cs_usolve / cs_ltsolve / cs_lusol / cs_cholsol) -

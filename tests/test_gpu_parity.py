@@ -388,3 +388,58 @@ def test_fresh_handles_reproduce_bitwise_on_big_fronts(gpu):
         assert all(np.array_equal(a, c) for a, c in zip(got, ref))
     A = csc_to_scipy(m, n, Ap, Ai, Ax)
     assert np.abs(A @ ref[0] - b).max() <= 1e-11 * np.abs(b).max() * n
+
+
+@pytest.mark.parametrize("case", ["grid20k_lu", "denseblock_lu", "spd_chol"])
+@pytest.mark.parametrize("nrhs", [1, 5])
+def test_factor_solve_fused_equals_factor_then_solve(gpu, case, nrhs):
+    """cs3_factor_solve_dev (forward sweep overlapped with the factorisation) == factor_dev + solve_dev, bit for bit."""
+    import torch
+    if case == "grid20k_lu":
+        m, n, Ap, Ai, Ax = synth.grid_jacobian(n=20000, seed=20000)
+        kind = gpu.CS3_LU
+    elif case == "denseblock_lu":
+        m, n, Ap, Ai, Ax = synth.dense_block_matrix(n=1500, nd=650, seed=5)
+        kind = gpu.CS3_LU
+    else:
+        ei, ej = synth.spd_grid_pattern(5000, seed=3)
+        m, n, Ap, Ai, Ax = synth.spd_grid_matrix(5000, ei, ej, seed=4)
+        kind = gpu.CS3_CHOLESKY
+    b = np.random.default_rng(nrhs).standard_normal((n, nrhs) if nrhs > 1 else n)
+    dev = torch.device("cuda", 0)
+    sh = torch.cuda.current_stream().cuda_stream
+    d_ax = torch.from_numpy(Ax).to(dev)
+    with gpu.Factorization(m, n, Ap, Ai, kind) as F:
+        x_split = torch.from_numpy(b).to(dev)
+        F.factor_dev(d_ax.data_ptr(), 1e-3, sh)
+        F.solve_dev(x_split.data_ptr(), nrhs, sh)
+        F.factor_status(sh)
+        for _ in range(3):                         # first call captures, later calls replay
+            x_fused = torch.from_numpy(b).to(dev)
+            F.factor_solve_dev(d_ax.data_ptr(), x_fused.data_ptr(), nrhs, 1e-3, sh)
+            F.factor_status(sh)
+            assert torch.equal(x_fused, x_split)
+        Lx_a = F.factors()[2]
+    with gpu.Factorization(m, n, Ap, Ai, kind) as G:   # fused as the very first call on a handle
+        x0 = torch.from_numpy(b).to(dev)
+        G.factor_solve_dev(d_ax.data_ptr(), x0.data_ptr(), nrhs, 1e-3, sh)
+        G.factor_status(sh)
+        assert torch.equal(x0, x_split)
+        assert np.array_equal(G.factors()[2], Lx_a)
+    A = csc_to_scipy(m, n, Ap, Ai, Ax)
+    x = x_split.cpu().numpy()
+    assert np.abs(A @ x - b).max() <= 1e-10 * max(1.0, np.abs(b).max()) * np.sqrt(n)
+
+
+def test_factor_solve_fused_reports_rejected_pivot(gpu):
+    import torch
+    m, n, Ap, Ai, Ax = synth.jacobian_like()
+    Ax = Ax.copy()
+    Ax[:] = 0.0
+    dev = torch.device("cuda", 0)
+    sh = torch.cuda.current_stream().cuda_stream
+    with gpu.Factorization(m, n, Ap, Ai) as F:
+        x = torch.ones(n, dtype=torch.float64, device=dev)
+        F.factor_solve_dev(torch.from_numpy(Ax).to(dev).data_ptr(), x.data_ptr(), 1, 1e-3, sh)
+        with pytest.raises(gpu.SingularMatrix):
+            F.factor_status(sh)

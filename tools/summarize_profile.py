@@ -11,7 +11,7 @@ import shutil
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 45          # --steps 40 + --warmup 5
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 86          # 1 capture + 5 warmup + 40 timed + 40 phase-pass steps
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
@@ -35,7 +35,7 @@ def per_kernel(kind):
 
 
 fetch, write = per_kernel("fetch"), per_kernel("write")
-factor_kernels = [n for n in fetch if n.startswith("k_front_lds") or n.startswith("k_big")]
+factor_kernels = [n for n in fetch if n.startswith("k_front") or n.startswith("k_big")]
 solve_kernels = [n for n in fetch if n.startswith("k_fwd") or n.startswith("k_bwd") or n.startswith("k_permute")]
 kb = lambda table, names: sum(table.get(n, {"kb_per_step": 0.0})["kb_per_step"] for n in names)
 # FETCH_SIZE / WRITE_SIZE are KB (x 1024).  Calibration on known byte counts in this very profile:

@@ -104,6 +104,7 @@ int ensure_device(cs3_handle h)
         f.lpan = S.lpan_off[s]; f.upan = S.upan_off[s]; f.cv = S.cv_off[s]; f.st = S.st_ptr[s];
         f.fasm_begin = S.fasm_ptr[s]; f.fasm_count = (int) (S.fasm_ptr[s + 1] - S.fasm_ptr[s]);
         f.bv = S.bv_off[s];
+        f.rl_begin = S.rl_ptr[s]; f.rl_count = (int) (S.rl_ptr[s + 1] - S.rl_ptr[s]);
         f.c0 = S.sn_ptr[s];
         f.r = (int) (S.st_ptr[s + 1] - S.st_ptr[s]);
         f.w = S.sn_ptr[s + 1] - S.sn_ptr[s];
@@ -115,13 +116,14 @@ int ensure_device(cs3_handle h)
     if ((rc = upload(&D.fasm_src, S.fasm_src))) return rc;
     if ((rc = upload(&D.fasm_tgt, S.fasm_tgt))) return rc;
     if ((rc = upload(&D.flong_src, S.flong_src))) return rc;
+    if ((rc = upload(&D.rl_pairs, S.rl_pairs))) return rc;
     if ((rc = upload(&D.fdesc, fdesc))) return rc;
     if ((rc = upload(&D.st_idx, S.st_idx))) return rc;
     if ((rc = upload(&D.asm_src, S.asm_src))) return rc;
     if ((rc = upload(&D.asm_tgt, S.asm_tgt))) return rc;
     if ((rc = upload(&D.long_src, S.long_src))) return rc;
     if ((rc = upload(&D.q, S.q))) return rc;
-    CS3_HIP(hipMalloc((void **) &D.pool, std::max<size_t>(1, (size_t) (D.batch * D.pool_size)) * sizeof(double)));
+    CS3_HIP(hipMalloc((void **) &D.pool, ((size_t) (D.batch * D.pool_size) + POOL_SLACK) * sizeof(double)));   // slack: see k_fwd_rhs
     CS3_HIP(hipMalloc((void **) &D.dbuf, std::max<size_t>(1, (size_t) (D.batch * D.dbuf_size)) * sizeof(double)));
     CS3_HIP(hipMalloc((void **) &D.ax, std::max<size_t>(1, (size_t) (D.batch * D.nnz_a)) * sizeof(double)));
     CS3_HIP(hipMalloc((void **) &D.status, sizeof(int)));
@@ -383,7 +385,7 @@ int cs3_free(cs3_handle h)
         if (h->cap_stream) (void) hipStreamDestroy(h->cap_stream);
         h->fj.destroy();
         void *ptrs[] = {D.fdesc, D.st_idx, D.asm_src, D.asm_tgt, D.long_src,
-                        D.sdesc, D.fasm_src, D.fasm_tgt, D.flong_src, D.q, D.ax, D.pool, D.dbuf, D.tbuf, D.bigv, D.cv, D.xp, D.status, h->d_lmap, h->d_umap, h->d_lx, h->d_ux};
+                        D.sdesc, D.fasm_src, D.fasm_tgt, D.flong_src, D.rl_pairs, D.q, D.ax, D.pool, D.dbuf, D.tbuf, D.bigv, D.cv, D.xp, D.status, h->d_lmap, h->d_umap, h->d_lx, h->d_ux};
         for (void *p : ptrs) if (p) (void) hipFree(p);
     }
     delete h;

@@ -20,10 +20,16 @@ struct FrontDesc {
     int parent;
 };
 
+// Doubles allocated past the end of the factor pool: the lane = right-hand-side sweeps read whole
+// 32-row columns of a panel whatever its height.
+constexpr size_t POOL_SLACK = 2048;
+
 // What the solve kernels read per front, in SOLVE-schedule order.
 struct SolveDesc {
     long long lpan, upan, cv, st, fasm_begin;
-    long long bv;                 // kind-2 fronts: offset of the full front vector in bigv
+    long long bv;                 // SK_BIG fronts: offset of the full front vector in bigv
+    long long rl_begin;           // SK_SMALL fronts: first (target, source) pair of the children's additions
+    int rl_count;                 //   pairs, a multiple of 16
     int fasm_count;
     int c0, r, w;
     int u_sk, u_sj;               // U(k, j) = pool[upan + k*u_sk + (j-w)*u_sj]
@@ -41,6 +47,7 @@ struct DeviceFactor {
     int *asm_src = nullptr, *asm_tgt = nullptr, *long_src = nullptr;
     SolveDesc *sdesc = nullptr;
     int *fasm_src = nullptr, *fasm_tgt = nullptr, *flong_src = nullptr;
+    int *rl_pairs = nullptr;
     int *q = nullptr;             // [n] pivot order
     double *ax = nullptr;         // [batch][nnz_a] values of A (stable address for the graph)
     double *pool = nullptr;       // [batch][pool_size]  factors | contribution blocks

@@ -32,6 +32,16 @@ void cholesky_counts(i64 n, const i32 *Ap, const i32 *Ai, const i32 *parent,
 // Size classes of fronts; each class is one kernel configuration.
 enum FrontClass : int { FC_R16 = 0, FC_R32 = 1, FC_R64 = 2, FC_LDS = 3, FC_BIG = 4, FC_COUNT = 5 };
 
+// Solve kernels by front shape.  SK_SMALL and SK_WAVE share the one-wave-per-front kernels for few
+// right-hand sides (adjacent in the schedule, launched as one group); with many right-hand sides
+// SK_SMALL fronts run lane = right-hand side.
+enum SolveKind : int {
+    SK_SMALL = 0,      // r <= 32
+    SK_WAVE = 1,       // r <= 128, w <= 64
+    SK_BLOCK = 2,      // one workgroup per front
+    SK_BIG = 3         // w > 64, r > 136: one launch per 64-column chunk, many workgroups
+};
+
 struct LaunchGroup {          // fronts of one level that share a kernel configuration
     int level;
     int cls;                  // FrontClass
@@ -80,10 +90,10 @@ struct Symbolic {
     // (src >= 0: entry of the contribution-vector pool; src < 0: row ~src of X)
     std::vector<i64> fasm_ptr;
     std::vector<i32> fasm_src, fasm_tgt, flong_src;
-    // solve schedule: supernodes by (level, kind); kind 0 = one wave per front
-    // (r <= 128, w <= 64), kind 1 = one workgroup per front, kind 2 = wide big fronts
-    // (w > 64, r > 136): one launch per 64-column chunk, many workgroups
+    // solve schedule: supernodes by (level, kind), see SolveKind
     std::vector<i32> ssched;
+    std::vector<i64> rl_ptr;                  // SK_SMALL fronts: children's additions as (target, source) pairs
+    std::vector<i32> rl_pairs;                //   sorted by target, padded to multiples of 16 with target -1
     std::vector<i64> bv_off;                  // kind-2 fronts: offset of their full front vector in the bigv buffer
     i64 bv_size = 0;
     std::vector<LaunchGroup> sgroups;

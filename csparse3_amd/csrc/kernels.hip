@@ -40,6 +40,8 @@ __device__ __forceinline__ double load_if(const double *__restrict__ p, long lon
     return ok ? v : 0.0;
 }
 
+__device__ __forceinline__ int bcast_lane_i(int x, int k) { return __builtin_amdgcn_readlane(x, k); }   // k wave-uniform
+
 __device__ __forceinline__ double bcast_lane(double x, int k)     // k wave-uniform
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), k);
@@ -889,6 +891,195 @@ k_bwd_wave(const SolveDesc *__restrict__ sd, int first, int count, const int *__
         if (lane < w && q < nlive) X[(long long) (d.c0 + lane) * nrhs + t0 + q] = v0[q];
 }
 
+// ---------------------------------------------------------------- many right-hand sides --
+// Fronts of order r <= 32 with 16 or more right-hand sides: one wave per (front, tile of 64
+// right-hand sides), LANE = RIGHT-HAND SIDE.  X and the contribution vectors are [row][rhs], so a
+// row of the tile is one coalesced 512-byte access and every lane runs the same scalar recurrence
+// on its own column: no cross-lane traffic in the data.  (The lane = row kernels above serve 8
+// right-hand sides per pass.)
+//   * the front vector sits in statically indexed registers; only the assembly, whose targets are
+//     data, goes through LDS, where each lane touches nothing but its own column;
+//   * the panel is the same for every lane.  It is fetched ONCE, zero-padded, by one round of
+//     coalesced vector loads into RMAX/2 registers (lane = row + 32 * (column & 1), register =
+//     column / 2) and its entries reach the FMAs by v_readlane.  Scalar loads would feed the FMAs
+//     for free, but a lone wave then waits out ~60 scalar-cache misses per front (measured: 30 us
+//     per launch whatever the level's size);
+//   * the children's additions come as (target, source) pairs sorted by target: pairs are loaded 64
+//     at a time as vectors, rows 16 at a time with the next 16 already in flight.
+template <int RMAX>
+__device__ __forceinline__ void load_panel_regs(double (&P)[RMAX / 2], const double *__restrict__ L, int r, int w, int lane)
+{
+    const int i = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < RMAX / 2; ++q) {
+        const int k = 2 * q + kh;
+        P[q] = load_if(L, i + (long long) k * r, i < r && k < w);
+    }
+}
+// entry (i, k) of a panel held that way
+#define CS3_PANEL(P, i, k) bcast_lane((P)[(k) >> 1], (i) + 32 * ((k) & 1))
+
+template <int KIND, int RMAX>
+__global__ void __launch_bounds__(64)
+k_fwd_rhs(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ rl,
+          const double *__restrict__ pool_all, double *cv_all, double *X_all,
+          int nrhs, long long pool_stride, long long cv_stride, long long x_stride)
+{
+    __shared__ double vl[RMAX * 64];
+    const SolveDesc d = sd[first + blockIdx.x];
+    const int lane = threadIdx.x;
+    const int col = blockIdx.z * 64 + lane;
+    const bool live = col < nrhs;
+    const long long lo = live ? col : 0;
+    const double *pool = pool_all + (long long) blockIdx.y * pool_stride;
+    double *cv = cv_all + (long long) blockIdx.y * cv_stride;
+    double *X = X_all + (long long) blockIdx.y * x_stride;
+    const int r = d.r, w = d.w;
+    const double *L = pool + d.lpan;
+    double P[RMAX / 2];
+    load_panel_regs<RMAX>(P, L, r, w, lane);
+    double rd = 1.0;
+    if (KIND == CS3_CHOLESKY) rd = L[(lane < w ? lane : 0) * (long long) (r + 1)];
+    // own rows of X, zeros below them
+#pragma unroll
+    for (int t = 0; t < RMAX; ++t) {
+        double x0 = 0.0;
+        if (t < w) x0 = X[(long long) (d.c0 + t) * nrhs + lo];
+        vl[t * 64 + lane] = x0;
+    }
+    // what the children add, sorted by target: sum a run in a register, add it once
+    {
+        const int np = d.rl_count;                             // multiple of 16
+        const int *pr = rl + 2 * d.rl_begin;
+        int cur = -1;
+        double acc = 0.0;
+        for (int base = 0; base < np; base += 64) {
+            const int have = min(64, np - base);
+            const int e = base + (lane < have ? lane : 0);
+            const int ptg = pr[2 * e], psr = pr[2 * e + 1];    // pair `lane` of this block of 64
+            double nxt[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) nxt[u] = cv[(long long) bcast_lane_i(psr, u) * nrhs + lo];
+            for (int c = 0; c < have; c += 16) {
+                double val[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) val[u] = nxt[u];
+                if (c + 16 < have) {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) nxt[u] = cv[(long long) bcast_lane_i(psr, c + 16 + u) * nrhs + lo];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int tg = bcast_lane_i(ptg, c + u);
+                    if (tg != cur) {                           // wave-uniform
+                        if (cur >= 0) vl[cur * 64 + lane] += acc;
+                        cur = tg; acc = 0.0;
+                    }
+                    acc += (tg >= 0) ? val[u] : 0.0;
+                }
+            }
+        }
+        if (cur >= 0) vl[cur * 64 + lane] += acc;
+    }
+    double v[RMAX];
+#pragma unroll
+    for (int t = 0; t < RMAX; ++t) v[t] = vl[t * 64 + lane];
+    if (KIND == CS3_CHOLESKY) rd = 1.0 / rd;                   // 1 / L(k, k), pivot k in lane k
+#pragma unroll
+    for (int k = 0; k < RMAX; ++k) {
+        if (k < w) {
+            if (KIND == CS3_CHOLESKY) v[k] *= bcast_lane(rd, k);
+#pragma unroll
+            for (int i0 = (k + 1) & ~7; i0 < RMAX; i0 += 8) {
+                if (i0 < r) {
+#pragma unroll
+                    for (int i = (i0 > k + 1 ? i0 : k + 1); i < i0 + 8; ++i) v[i] -= CS3_PANEL(P, i, k) * v[k];
+                }
+            }
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int t = 0; t < RMAX; ++t)
+        if (t < w) X[(long long) (d.c0 + t) * nrhs + col] = v[t];
+    if (d.parent >= 0) {
+#pragma unroll
+        for (int t = 0; t < RMAX; ++t)
+            if (t >= w && t < r) cv[(d.cv + t - w) * nrhs + col] = v[t];
+    }
+}
+
+template <int KIND, int RMAX>
+__global__ void __launch_bounds__(64)
+k_bwd_rhs(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ st_idx,
+          const double *__restrict__ pool_all, double *X_all,
+          int nrhs, long long pool_stride, long long x_stride)
+{
+    const SolveDesc d = sd[first + blockIdx.x];
+    const int lane = threadIdx.x;
+    const int col = blockIdx.z * 64 + lane;
+    const bool live = col < nrhs;
+    const long long lo = live ? col : 0;
+    const double *pool = pool_all + (long long) blockIdx.y * pool_stride;
+    double *X = X_all + (long long) blockIdx.y * x_stride;
+    const int r = d.r, w = d.w, nb = r - w;
+    const double *L = pool + d.lpan;
+    const double *U = pool + d.upan;
+    // ancestor rows: index `lane` of the row structure in lane `lane`
+    const int myrow = st_idx[d.st + w + (lane < nb ? lane : 0)];
+    double P[RMAX / 2], Q[RMAX / 2];           // diagonal block; U12 (Cholesky: L21'), entry (i, j) at lane i + 32 (j & 1), register j / 2
+    load_panel_regs<RMAX>(P, L, r, w, lane);
+    {
+        const int i = lane & 31, jh = lane >> 5;
+#pragma unroll
+        for (int q = 0; q < RMAX / 2; ++q) {
+            const int j = 2 * q + jh;
+            const long long off = (KIND == CS3_LU) ? (long long) i * d.u_sk + (long long) j * d.u_sj
+                                                   : (long long) (w + j) + (long long) i * r;
+            Q[q] = load_if((KIND == CS3_LU) ? U : L, off, i < w && j < nb);
+        }
+    }
+    double rd = L[(lane < w ? lane : 0) * (long long) (r + 1)];
+    double v[RMAX], a[RMAX];                   // pivot rows; ancestor rows (already solved)
+#pragma unroll
+    for (int t = 0; t < RMAX; ++t) {
+        v[t] = 0.0; a[t] = 0.0;
+        if (t < w) v[t] = X[(long long) (d.c0 + t) * nrhs + lo];
+        if (t < nb) a[t] = X[(long long) bcast_lane_i(myrow, t) * nrhs + lo];
+    }
+    rd = 1.0 / rd;
+    // v -= U12 a   (Cholesky: L21' a)
+#pragma unroll
+    for (int j0 = 0; j0 < RMAX; j0 += 8) {
+        if (j0 < nb) {
+#pragma unroll
+            for (int i0 = 0; i0 < RMAX; i0 += 8) {
+                if (i0 < w) {
+#pragma unroll
+                    for (int j = j0; j < j0 + 8; ++j)
+#pragma unroll
+                        for (int i = i0; i < i0 + 8; ++i) v[i] -= CS3_PANEL(Q, i, j) * a[j];
+                }
+            }
+        }
+    }
+    // back substitution with U11 (Cholesky: L11'), reciprocal pivots from one vector division
+#pragma unroll
+    for (int k = RMAX - 1; k >= 0; --k) {
+        if (k < w) {
+            v[k] *= bcast_lane(rd, k);
+#pragma unroll
+            for (int i = 0; i < k; ++i)
+                v[i] -= ((KIND == CS3_LU) ? CS3_PANEL(P, i, k) : CS3_PANEL(P, k, i)) * v[k];
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int t = 0; t < RMAX; ++t)
+        if (t < w) X[(long long) (d.c0 + t) * nrhs + col] = v[t];
+}
+#undef CS3_PANEL
+
 // One workgroup per front (any size): the front vector lives in LDS, the pivot
 // block is walked in chunks of 64 columns -- wave 0 solves the 64 x 64 triangle
 // with every lane owning one row (whole row prefetched, shuffles for y_k), then
@@ -1503,13 +1694,32 @@ hipError_t launch_factor_levels(const DeviceFactor &D, const std::vector<LaunchG
     return hipSuccess;
 }
 
+constexpr int RHS_LANES_MIN = 16;          // from this many right-hand sides on, SK_SMALL fronts run lane = right-hand side
+
+template <int KIND, int RMAX>
+static void launch_rhs_sweep(const DeviceFactor &D, const LaunchGroup &g, double *X, int nrhs, bool forward, hipStream_t st)
+{
+    const long long xs = D.n * (long long) nrhs, cvs = D.cv_size * (long long) nrhs;
+    dim3 grid((unsigned) g.count, (unsigned) D.batch, (unsigned) ((nrhs + 63) / 64));
+    if (forward)
+        hipLaunchKernelGGL((k_fwd_rhs<KIND, RMAX>), grid, dim3(64), 0, st, D.sdesc, g.first, D.rl_pairs, D.pool, D.cv, X,
+                           nrhs, D.pool_size, cvs, xs);
+    else
+        hipLaunchKernelGGL((k_bwd_rhs<KIND, RMAX>), grid, dim3(64), 0, st, D.sdesc, g.first, D.st_idx, D.pool, X,
+                           nrhs, D.pool_size, xs);
+}
+
 template <int KIND>
 static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g, double *X, int nrhs,
                                      bool forward, hipStream_t st)
 {
     const long long xs = D.n * (long long) nrhs;
     const long long cvs = D.cv_size * (long long) nrhs;
-    if (g.cls == 0) {
+    if (g.cls == SK_SMALL && nrhs >= RHS_LANES_MIN) {
+        if (g.max_r <= 16) launch_rhs_sweep<KIND, 16>(D, g, X, nrhs, forward, st);
+        else if (g.max_r <= 24) launch_rhs_sweep<KIND, 24>(D, g, X, nrhs, forward, st);
+        else launch_rhs_sweep<KIND, 32>(D, g, X, nrhs, forward, st);
+    } else if (g.cls == SK_SMALL || g.cls == SK_WAVE) {
         if (nrhs == 1) {
             dim3 grid((unsigned) ((g.count + 3) / 4), (unsigned) D.batch, 1);
             if (forward)
@@ -1528,7 +1738,7 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
                 hipLaunchKernelGGL((k_bwd_wave<KIND, KT>), grid, dim3(256), 0, st, D.sdesc, g.first, g.count, D.st_idx,
                                    D.pool, X, nrhs, D.pool_size, xs);
         }
-    } else if (g.cls == 2) {
+    } else if (g.cls == SK_BIG) {
         const unsigned by = (unsigned) (D.batch * nrhs);
         const int nchunk = (g.max_w + SOLVE_BW - 1) / SOLVE_BW;
         const int slices = std::max(1, (g.max_r + 63) / 64);
@@ -1570,9 +1780,29 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
     return hipSuccess;
 }
 
-hipError_t launch_solve_levels(const DeviceFactor &D, const std::vector<LaunchGroup> &groups,
+// With few right-hand sides SK_SMALL and SK_WAVE fronts share the one-wave-per-front kernels:
+// the two groups of a level are adjacent in the schedule and go out as one launch.
+static std::vector<LaunchGroup> sweep_groups(const std::vector<LaunchGroup> &groups, int nrhs)
+{
+    if (nrhs >= RHS_LANES_MIN) return groups;
+    std::vector<LaunchGroup> out;
+    for (const LaunchGroup &g : groups) {
+        if (!out.empty() && out.back().level == g.level && out.back().cls == SK_SMALL && g.cls == SK_WAVE &&
+            out.back().first + out.back().count == g.first) {
+            LaunchGroup &m = out.back();
+            m.cls = SK_WAVE; m.count += g.count;
+            m.max_r = std::max(m.max_r, g.max_r); m.max_w = std::max(m.max_w, g.max_w);
+        } else {
+            out.push_back(g);
+        }
+    }
+    return out;
+}
+
+hipError_t launch_solve_levels(const DeviceFactor &D, const std::vector<LaunchGroup> &all_groups,
                                double *X, int nrhs, bool forward, hipStream_t st, ForkJoin &fj)
 {
+    const std::vector<LaunchGroup> groups = sweep_groups(all_groups, nrhs);
     fj.rewind();
     // the sweeps' per-level launches are short: fork/join costs more than it hides (measured), so they stay in line
     static const bool solve_parallel = getenv("CS3_SOLVE_FORK") && getenv("CS3_SOLVE_FORK")[0] == '1';
@@ -1607,7 +1837,7 @@ static int factor_group_cost(const LaunchGroup &g)
 }
 static int sweep_group_cost(const LaunchGroup &g)
 {
-    return (g.cls == 2) ? 2 + (g.max_w + SOLVE_BW - 1) / SOLVE_BW : 1;
+    return (g.cls == SK_BIG) ? 2 + (g.max_w + SOLVE_BW - 1) / SOLVE_BW : 1;
 }
 
 // Factorisation with the forward sweep partly hidden behind it.  The sweep of levels 0..K needs only
@@ -1616,9 +1846,10 @@ static int sweep_group_cost(const LaunchGroup &g)
 // K is the last level whose tail is still long enough to cover the sweep; one fork, one join -- a
 // fork per level costs more than it hides (measured).  Same kernels, same operands: same bits.
 hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<LaunchGroup> &fgroups,
-                                      const std::vector<LaunchGroup> &sgroups, double inv_tol, double *X, int nrhs,
+                                      const std::vector<LaunchGroup> &all_sgroups, double inv_tol, double *X, int nrhs,
                                       hipStream_t st, ForkJoin &fj)
 {
+    const std::vector<LaunchGroup> sgroups = sweep_groups(all_sgroups, nrhs);
     fj.rewind();
     hipError_t e;
     if (D.vals_size > D.big_begin) {

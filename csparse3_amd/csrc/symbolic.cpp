@@ -13,6 +13,8 @@
 #include <stdexcept>
 
 #include "cs3_internal.hpp"
+#include <cstdio>
+#include <cstdlib>
 
 namespace cs3 {
 
@@ -307,18 +309,30 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     for (i32 s = 0; s < nf; ++s) {
         mw[s] = fsn_ptr[s + 1] - fsn_ptr[s]; mr[s] = fst_ptr[s + 1] - fst_ptr[s]; mc0[s] = fsn_ptr[s];
     }
-    const i64 lds_r = 136;
-    for (i32 s = 0; s < nf; ++s) {
-        const i32 p = fparent[s];
-        if (p < 0 || fsn_ptr[s + 1] != mc0[p]) continue;       // not the last child of (merged) p
-        const i64 wn = mw[s] + mw[p], rn = mw[s] + mr[p], nbs = mr[s] - mw[s];
-        const double zn = mz[s] + mz[p] + (double) mw[s] * (double) (mr[p] - nbs);
-        const double tn = (double) wn * (double) rn - 0.5 * (double) wn * (double) (wn - 1);
-        bool ok = (wn <= relax_w) || (zn <= relax_z * tn);
-        if (rn > lds_r && std::max(mr[s], mr[p]) <= lds_r) ok = false;   // do not push a resident front out of the LDS
-        if (rn > relax_r && rn <= lds_r && wn > relax_w && zn > relax_z2 * tn) ok = false;
-        if (!ok) continue;
-        mw[p] = wn; mr[p] = rn; mz[p] = zn; mc0[p] = mc0[s]; alive[s] = 0;
+    const i64 lds_r = 136, big_nb = 32;
+    std::vector<i32> into(nf, -1);           // merged-into link; the alive supernode is the top of its chain
+    auto alive_of = [&](i32 f) { while (into[f] >= 0) f = into[f]; return f; };
+    i64 relax_passes = 4;                    // later passes see parents at their merged size (a thin first member of a
+    if (const char *e = std::getenv("CS3_RELAX_PASSES")) relax_passes = std::atoll(e);   // wide root hides how cheap a merge is)
+    for (i64 pass = 0; pass < relax_passes; ++pass) {
+        bool changed = false;
+        for (i32 s = 0; s < nf; ++s) {
+            if (!alive[s] || fparent[s] < 0) continue;
+            const i32 p = alive_of(fparent[s]);
+            if (fsn_ptr[s + 1] != mc0[p]) continue;                // not the last child of (merged) p
+            const i64 wn = mw[s] + mw[p], rn = mw[s] + mr[p], nbs = mr[s] - mw[s];
+            const double zn = mz[s] + mz[p] + (double) mw[s] * (double) (mr[p] - nbs);
+            const double tn = (double) wn * (double) rn - 0.5 * (double) wn * (double) (wn - 1);
+            bool ok = (wn <= relax_w) || (zn <= relax_z * tn);
+            if (rn > lds_r && std::max(mr[s], mr[p]) <= lds_r) ok = false;   // do not push a resident front out of the LDS
+            if (rn > relax_r && rn <= lds_r && wn > relax_w && zn > relax_z2 * tn) ok = false;
+            // a blocked big front pays per block of big_nb pivots: absorb a child only into the slack of the last block
+            if (pass > 0 && mr[p] > lds_r && (wn + big_nb - 1) / big_nb > (mw[p] + big_nb - 1) / big_nb) ok = false;
+            if (!ok) continue;
+            mw[p] = wn; mr[p] = rn; mz[p] = zn; mc0[p] = mc0[s]; alive[s] = 0; into[s] = p;
+            changed = true;
+        }
+        if (!changed) break;
     }
     S.col2sn.resize(n);
     S.sn_ptr.clear();
@@ -568,12 +582,36 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         }
     }
     auto solve_kind = [&](i32 s) {
-        if (order_r(s) <= 128 && width(s) <= 64) return 0;
-        return (width(s) > 64 && order_r(s) > 136) ? 2 : 1;
+        if (order_r(s) <= 32) return (int) SK_SMALL;
+        if (order_r(s) <= 128 && width(s) <= 64) return (int) SK_WAVE;
+        return (width(s) > 64 && order_r(s) > 136) ? (int) SK_BIG : (int) SK_BLOCK;
     };
     S.bv_off.assign(ns, 0); S.bv_size = 0;
     for (i32 s = 0; s < ns; ++s)
-        if (solve_kind(s) == 2) { S.bv_off[s] = S.bv_size; S.bv_size += order_r(s); }
+        if (solve_kind(s) == SK_BIG) { S.bv_off[s] = S.bv_size; S.bv_size += order_r(s); }
+    // many right-hand sides, fronts of order <= 32 (lane = right-hand side): what the children add to
+    // the front vector as plain (target, source) pairs sorted by target, padded to a multiple of 16
+    // with target -1
+    S.rl_ptr.assign(ns + 1, 0);
+    S.rl_pairs.clear();
+    {
+        std::vector<Item> items;
+        for (i32 s = 0; s < ns; ++s) {
+            if (solve_kind(s) == SK_SMALL) {
+                items.clear();
+                for (i32 cp = S.child_ptr[s]; cp < S.child_ptr[s + 1]; ++cp) {
+                    const i32 c = S.child_idx[cp];
+                    const i64 nbc = order_r(c) - width(c);
+                    const i32 *rel = S.rel_idx.data() + S.rel_ptr[c];
+                    for (i64 ii = 0; ii < nbc; ++ii) items.push_back(Item{rel[ii], (i32) (S.cv_off[c] + ii)});
+                }
+                std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.tgt < b.tgt; });
+                for (const Item &it : items) { S.rl_pairs.push_back(it.tgt); S.rl_pairs.push_back(it.src); }
+                while ((S.rl_pairs.size() / 2) % 16) { S.rl_pairs.push_back(-1); S.rl_pairs.push_back(0); }
+            }
+            S.rl_ptr[s + 1] = (i64) (S.rl_pairs.size() / 2);
+        }
+    }
     S.ssched.resize(ns);
     std::iota(S.ssched.begin(), S.ssched.end(), 0);
     std::stable_sort(S.ssched.begin(), S.ssched.end(), [&](i32 a, i32 b) {
@@ -592,6 +630,14 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         }
         g.count = t - g.first;
         S.sgroups.push_back(g);
+    }
+
+    if (getenv("CS3_DUMP_GROUPS")) {
+        for (const LaunchGroup &g : S.groups)
+            fprintf(stderr, "factor level %2d cls %d count %6d max_r %4d max_w %4d max_asm %lld\n", g.level, g.cls, g.count,
+                    g.max_r, g.max_w, (long long) g.max_asm);
+        for (const LaunchGroup &g : S.sgroups)
+            fprintf(stderr, "solve  level %2d kind %d count %6d max_r %4d max_w %4d\n", g.level, g.cls, g.count, g.max_r, g.max_w);
     }
 
     // ---- 11. factors in CSC form: L diagonal first, U diagonal last.  Only the

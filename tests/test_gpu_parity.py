@@ -443,3 +443,60 @@ def test_factor_solve_fused_reports_rejected_pivot(gpu):
         F.factor_solve_dev(torch.from_numpy(Ax).to(dev).data_ptr(), x.data_ptr(), 1, 1e-3, sh)
         with pytest.raises(gpu.SingularMatrix):
             F.factor_status(sh)
+
+
+# ----------------------------------------- many right-hand sides (config 4) --
+
+@pytest.mark.parametrize("name", ["jacobian118", "grid2k", "grid20k", "denseblock300"])
+@pytest.mark.parametrize("k", [16, 70, 128])
+def test_many_rhs_lu_matches_oracle(gpu, orc, name, k):
+    """16 or more right-hand sides take the lane = right-hand-side sweeps on fronts of order <= 32;
+    every column must equal the oracle's solve, and the one-column path, to the parity tolerance."""
+    m, n, Ap, Ai, Ax = CASES[name]
+    B = np.random.default_rng(k).standard_normal((n, k))
+    with gpu.Factorization(m, n, Ap, Ai) as F:
+        F.factor(Ax, 1e-3)
+        Lp, Li, Lx, Up, Ui, Ux = F.factors()
+        X = F.solve(B)
+        Y = F.lsolve(B)
+        Z = F.usolve(Y)
+        x7 = F.solve(np.ascontiguousarray(B[:, 7]))
+    assert X.shape == (n, k) and not np.isnan(X).any()
+    for j in (0, 7, k - 1):
+        w = B[:, j].copy(); orc.csc_lsolve_f(n, Lp, Li, Lx, w)
+        assert rel_err(Y[:, j], w) <= RTOL
+        orc.csc_usolve_f(n, Up, Ui, Ux, w)
+        assert rel_err(Z[:, j], w) <= RTOL
+    assert rel_err(X[:, 7], x7) <= 1e-12
+    A = csc_to_scipy(m, n, Ap, Ai, Ax)
+    assert np.abs(A @ X - B).max() <= 1e-11 * np.abs(B).max() * n
+
+
+@pytest.mark.parametrize("name", list(SPD))
+@pytest.mark.parametrize("k", [16, 100])
+def test_many_rhs_cholesky(gpu, name, k):
+    m, n, Ap, Ai, Ax = SPD[name]
+    B = np.random.default_rng(k + 1).standard_normal((n, k))
+    with gpu.Factorization(m, n, Ap, Ai, kind=gpu.CS3_CHOLESKY) as F:
+        F.factor(Ax)
+        X = F.solve(B)
+        x3 = F.solve(np.ascontiguousarray(B[:, 3]))
+    A = csc_to_scipy(m, n, Ap, Ai, Ax)
+    assert np.abs(A @ X - B).max() <= 1e-11 * np.abs(B).max() * n
+    assert rel_err(X[:, 3], x3) <= 1e-12
+
+
+def test_many_rhs_batch_of_matrices(gpu):
+    n = 1500
+    ei, ej = synth.spd_grid_pattern(n, seed=77)
+    mats = [synth.spd_grid_matrix(n, ei, ej, seed=100 + i) for i in range(3)]
+    m, n, Ap, Ai, _ = mats[0]
+    AX = np.stack([mm[4] for mm in mats])
+    B = np.random.default_rng(5).standard_normal((3, n, 40))
+    for kind in (gpu.CS3_LU, gpu.CS3_CHOLESKY):
+        with gpu.Factorization(m, n, Ap, Ai, kind=kind, batch=3) as F:
+            F.factor(AX, 1e-3 if kind == gpu.CS3_LU else 0.0)
+            X = F.solve(B)
+        for i in range(3):
+            A = csc_to_scipy(m, n, Ap, Ai, AX[i])
+            assert np.abs(A @ X[i] - B[i]).max() <= 1e-11 * n

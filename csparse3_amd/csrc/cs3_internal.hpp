@@ -36,7 +36,7 @@ enum FrontClass : int { FC_R16 = 0, FC_R32 = 1, FC_R64 = 2, FC_LDS = 3, FC_BIG =
 // right-hand sides (adjacent in the schedule, launched as one group); with many right-hand sides
 // SK_SMALL fronts run lane = right-hand side.
 enum SolveKind : int {
-    SK_SMALL = 0,      // r <= 32
+    SK_SMALL = 0,      // r <= 64
     SK_WAVE = 1,       // r <= 128, w <= 64
     SK_BLOCK = 2,      // one workgroup per front
     SK_BIG = 3         // w > 64, r > 136: one launch per 64-column chunk, many workgroups

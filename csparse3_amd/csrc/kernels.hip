@@ -892,7 +892,7 @@ k_bwd_wave(const SolveDesc *__restrict__ sd, int first, int count, const int *__
 }
 
 // ---------------------------------------------------------------- many right-hand sides --
-// Fronts of order r <= 32 with 16 or more right-hand sides: one wave per (front, tile of 64
+// Fronts of order r <= 64 with 16 or more right-hand sides: one wave per (front, tile of 64
 // right-hand sides), LANE = RIGHT-HAND SIDE.  X and the contribution vectors are [row][rhs], so a
 // row of the tile is one coalesced 512-byte access and every lane runs the same scalar recurrence
 // on its own column: no cross-lane traffic in the data.  (The lane = row kernels above serve 8
@@ -900,27 +900,27 @@ k_bwd_wave(const SolveDesc *__restrict__ sd, int first, int count, const int *__
 //   * the front vector sits in statically indexed registers; only the assembly, whose targets are
 //     data, goes through LDS, where each lane touches nothing but its own column;
 //   * the panel is the same for every lane.  It is fetched ONCE, zero-padded, by one round of
-//     coalesced vector loads into RMAX/2 registers (lane = row + 32 * (column & 1), register =
-//     column / 2) and its entries reach the FMAs by v_readlane.  Scalar loads would feed the FMAs
+//     coalesced vector loads into registers (PanelRegs) and its entries reach the FMAs by v_readlane.  Scalar loads would feed the FMAs
 //     for free, but a lone wave then waits out ~60 scalar-cache misses per front (measured: 30 us
 //     per launch whatever the level's size);
 //   * the children's additions come as (target, source) pairs sorted by target: pairs are loaded 64
 //     at a time as vectors, rows 16 at a time with the next 16 already in flight.
-template <int RMAX>
-__device__ __forceinline__ void load_panel_regs(double (&P)[RMAX / 2], const double *__restrict__ L, int r, int w, int lane)
-{
-    const int i = lane & 31, kh = lane >> 5;
-#pragma unroll
-    for (int q = 0; q < RMAX / 2; ++q) {
-        const int k = 2 * q + kh;
-        P[q] = load_if(L, i + (long long) k * r, i < r && k < w);
+// A matrix M(i, t), i, t < RMAX, the same for every lane, held in registers: RMAX <= 32 packs two
+// columns per register (lane = i + 32 (t & 1), register = t / 2), RMAX = 64 one (lane = i).
+template <int RMAX> struct PanelRegs {
+    static constexpr int NREG = (RMAX <= 32) ? RMAX / 2 : RMAX;
+    double reg[NREG];
+    // lane's (row, column) in register q
+    static __device__ __forceinline__ int row_of(int lane) { return (RMAX <= 32) ? (lane & 31) : lane; }
+    static __device__ __forceinline__ int col_of(int lane, int q) { return (RMAX <= 32) ? 2 * q + (lane >> 5) : q; }
+    __device__ __forceinline__ double at(int i, int t) const     // i, t compile-time after unrolling
+    {
+        return (RMAX <= 32) ? bcast_lane(reg[t >> 1], i + 32 * (t & 1)) : bcast_lane(reg[t], i);
     }
-}
-// entry (i, k) of a panel held that way
-#define CS3_PANEL(P, i, k) bcast_lane((P)[(k) >> 1], (i) + 32 * ((k) & 1))
+};
 
 template <int KIND, int RMAX>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, (RMAX <= 32) ? 2 : 1)
 k_fwd_rhs(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ rl,
           const double *__restrict__ pool_all, double *cv_all, double *X_all,
           int nrhs, long long pool_stride, long long cv_stride, long long x_stride)
@@ -936,8 +936,15 @@ k_fwd_rhs(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ r
     double *X = X_all + (long long) blockIdx.y * x_stride;
     const int r = d.r, w = d.w;
     const double *L = pool + d.lpan;
-    double P[RMAX / 2];
-    load_panel_regs<RMAX>(P, L, r, w, lane);
+    PanelRegs<RMAX> P;                                         // P(i, k) = L(i, k), zero outside r x w
+    {
+        const int i = P.row_of(lane);
+#pragma unroll
+        for (int q = 0; q < P.NREG; ++q) {
+            const int k = P.col_of(lane, q);
+            P.reg[q] = load_if(L, i + (long long) k * r, i < r && k < w);
+        }
+    }
     double rd = 1.0;
     if (KIND == CS3_CHOLESKY) rd = L[(lane < w ? lane : 0) * (long long) (r + 1)];
     // own rows of X, zeros below them
@@ -993,7 +1000,7 @@ k_fwd_rhs(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ r
             for (int i0 = (k + 1) & ~7; i0 < RMAX; i0 += 8) {
                 if (i0 < r) {
 #pragma unroll
-                    for (int i = (i0 > k + 1 ? i0 : k + 1); i < i0 + 8; ++i) v[i] -= CS3_PANEL(P, i, k) * v[k];
+                    for (int i = (i0 > k + 1 ? i0 : k + 1); i < i0 + 8; ++i) v[i] -= P.at(i, k) * v[k];
                 }
             }
         }
@@ -1009,8 +1016,11 @@ k_fwd_rhs(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ r
     }
 }
 
+// Backward: the whole front vector x[0 .. r) in registers (pivot rows, then the ancestors' rows, which
+// are final), one descending recurrence  x[t] final -> x[i] -= M(i, t) x[t]  for the pivot rows i < t,
+// with M = [U11 U12] (Cholesky: [L11' L21']) and zero rows below w.
 template <int KIND, int RMAX>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, (RMAX <= 32) ? 2 : 1)
 k_bwd_rhs(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ st_idx,
           const double *__restrict__ pool_all, double *X_all,
           int nrhs, long long pool_stride, long long x_stride)
@@ -1022,63 +1032,50 @@ k_bwd_rhs(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ s
     const long long lo = live ? col : 0;
     const double *pool = pool_all + (long long) blockIdx.y * pool_stride;
     double *X = X_all + (long long) blockIdx.y * x_stride;
-    const int r = d.r, w = d.w, nb = r - w;
+    const int r = d.r, w = d.w;
     const double *L = pool + d.lpan;
     const double *U = pool + d.upan;
-    // ancestor rows: index `lane` of the row structure in lane `lane`
-    const int myrow = st_idx[d.st + w + (lane < nb ? lane : 0)];
-    double P[RMAX / 2], Q[RMAX / 2];           // diagonal block; U12 (Cholesky: L21'), entry (i, j) at lane i + 32 (j & 1), register j / 2
-    load_panel_regs<RMAX>(P, L, r, w, lane);
+    // row of X behind front position `lane`
+    const int myrow = (lane < w) ? d.c0 + lane : st_idx[d.st + (lane < r ? lane : 0)];
+    PanelRegs<RMAX> M;
     {
-        const int i = lane & 31, jh = lane >> 5;
+        const int i = M.row_of(lane);
 #pragma unroll
-        for (int q = 0; q < RMAX / 2; ++q) {
-            const int j = 2 * q + jh;
-            const long long off = (KIND == CS3_LU) ? (long long) i * d.u_sk + (long long) j * d.u_sj
-                                                   : (long long) (w + j) + (long long) i * r;
-            Q[q] = load_if((KIND == CS3_LU) ? U : L, off, i < w && j < nb);
+        for (int q = 0; q < M.NREG; ++q) {
+            const int t = M.col_of(lane, q);
+            long long off;
+            if (KIND == CS3_LU) off = (t < w) ? (long long) i + (long long) t * r
+                                              : (long long) i * d.u_sk + (long long) (t - w) * d.u_sj;
+            else off = (long long) t + (long long) i * r;
+            M.reg[q] = load_if((KIND == CS3_LU && t >= w) ? U : L, off, i < w && i <= t && t < r);
         }
     }
     double rd = L[(lane < w ? lane : 0) * (long long) (r + 1)];
-    double v[RMAX], a[RMAX];                   // pivot rows; ancestor rows (already solved)
+    double x[RMAX];
 #pragma unroll
     for (int t = 0; t < RMAX; ++t) {
-        v[t] = 0.0; a[t] = 0.0;
-        if (t < w) v[t] = X[(long long) (d.c0 + t) * nrhs + lo];
-        if (t < nb) a[t] = X[(long long) bcast_lane_i(myrow, t) * nrhs + lo];
+        x[t] = 0.0;
+        if (t < r) x[t] = X[(long long) bcast_lane_i(myrow, t) * nrhs + lo];
     }
-    rd = 1.0 / rd;
-    // v -= U12 a   (Cholesky: L21' a)
+    rd = 1.0 / rd;                                             // reciprocal pivots from one vector division
 #pragma unroll
-    for (int j0 = 0; j0 < RMAX; j0 += 8) {
-        if (j0 < nb) {
+    for (int t = RMAX - 1; t >= 0; --t) {
+        if (t < r) {
+            if (t < w) x[t] *= bcast_lane(rd, t);
 #pragma unroll
-            for (int i0 = 0; i0 < RMAX; i0 += 8) {
+            for (int i0 = 0; i0 < t; i0 += 8) {
                 if (i0 < w) {
 #pragma unroll
-                    for (int j = j0; j < j0 + 8; ++j)
-#pragma unroll
-                        for (int i = i0; i < i0 + 8; ++i) v[i] -= CS3_PANEL(Q, i, j) * a[j];
+                    for (int i = i0; i < i0 + 8 && i < t; ++i) x[i] -= M.at(i, t) * x[t];
                 }
             }
-        }
-    }
-    // back substitution with U11 (Cholesky: L11'), reciprocal pivots from one vector division
-#pragma unroll
-    for (int k = RMAX - 1; k >= 0; --k) {
-        if (k < w) {
-            v[k] *= bcast_lane(rd, k);
-#pragma unroll
-            for (int i = 0; i < k; ++i)
-                v[i] -= ((KIND == CS3_LU) ? CS3_PANEL(P, i, k) : CS3_PANEL(P, k, i)) * v[k];
         }
     }
     if (!live) return;
 #pragma unroll
     for (int t = 0; t < RMAX; ++t)
-        if (t < w) X[(long long) (d.c0 + t) * nrhs + col] = v[t];
+        if (t < w) X[(long long) (d.c0 + t) * nrhs + col] = x[t];
 }
-#undef CS3_PANEL
 
 // One workgroup per front (any size): the front vector lives in LDS, the pivot
 // block is walked in chunks of 64 columns -- wave 0 solves the 64 x 64 triangle
@@ -1716,9 +1713,9 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
     const long long xs = D.n * (long long) nrhs;
     const long long cvs = D.cv_size * (long long) nrhs;
     if (g.cls == SK_SMALL && nrhs >= RHS_LANES_MIN) {
-        if (g.max_r <= 16) launch_rhs_sweep<KIND, 16>(D, g, X, nrhs, forward, st);
-        else if (g.max_r <= 24) launch_rhs_sweep<KIND, 24>(D, g, X, nrhs, forward, st);
-        else launch_rhs_sweep<KIND, 32>(D, g, X, nrhs, forward, st);
+        if (g.max_r <= 24) launch_rhs_sweep<KIND, 24>(D, g, X, nrhs, forward, st);
+        else if (g.max_r <= 32) launch_rhs_sweep<KIND, 32>(D, g, X, nrhs, forward, st);
+        else launch_rhs_sweep<KIND, 64>(D, g, X, nrhs, forward, st);
     } else if (g.cls == SK_SMALL || g.cls == SK_WAVE) {
         if (nrhs == 1) {
             dim3 grid((unsigned) ((g.count + 3) / 4), (unsigned) D.batch, 1);

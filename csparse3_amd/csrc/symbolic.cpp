@@ -582,14 +582,14 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         }
     }
     auto solve_kind = [&](i32 s) {
-        if (order_r(s) <= 32) return (int) SK_SMALL;
+        if (order_r(s) <= 64) return (int) SK_SMALL;
         if (order_r(s) <= 128 && width(s) <= 64) return (int) SK_WAVE;
         return (width(s) > 64 && order_r(s) > 136) ? (int) SK_BIG : (int) SK_BLOCK;
     };
     S.bv_off.assign(ns, 0); S.bv_size = 0;
     for (i32 s = 0; s < ns; ++s)
         if (solve_kind(s) == SK_BIG) { S.bv_off[s] = S.bv_size; S.bv_size += order_r(s); }
-    // many right-hand sides, fronts of order <= 32 (lane = right-hand side): what the children add to
+    // many right-hand sides, fronts of order <= 64 (lane = right-hand side): what the children add to
     // the front vector as plain (target, source) pairs sorted by target, padded to a multiple of 16
     // with target -1
     S.rl_ptr.assign(ns + 1, 0);

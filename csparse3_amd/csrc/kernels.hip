@@ -40,6 +40,14 @@ __device__ __forceinline__ double load_if(const double *__restrict__ p, long lon
     return ok ? v : 0.0;
 }
 
+// 1 / diagonal entry `i` of an r-row panel: the sweeps multiply by it (one division per lane instead
+// of one per pivot step executed by the whole wave)
+__device__ __forceinline__ double recip_diag(const double *__restrict__ L, long long i, long long r, bool ok)
+{
+    const double dg = L[ok ? i * (r + 1) : 0];
+    return 1.0 / (ok ? dg : 1.0);
+}
+
 __device__ __forceinline__ int bcast_lane_i(int x, int k) { return __builtin_amdgcn_readlane(x, k); }   // k wave-uniform
 
 __device__ __forceinline__ double bcast_lane(double x, int k)     // k wave-uniform
@@ -781,6 +789,7 @@ k_fwd_wave(const SolveDesc *__restrict__ sd, int first, int count,
 #pragma unroll
     for (int q = 0; q < KT; ++q) { v0[q] = vs[wv][q][lane]; v1[q] = vs[wv][q][lane + 64]; }
     const double *L = pool + d.lpan;
+    const double rdg = (KIND == CS3_CHOLESKY) ? recip_diag(L, lane, r, lane < w) : 1.0;
     for (int k0 = 0; k0 < w; k0 += SOLVE_PF) {
         double l0[SOLVE_PF], l1[SOLVE_PF];
 #pragma unroll
@@ -795,7 +804,7 @@ k_fwd_wave(const SolveDesc *__restrict__ sd, int first, int count,
             if (k < w) {
 #pragma unroll
                 for (int q = 0; q < KT; ++q) {
-                    if (KIND == CS3_CHOLESKY && lane == k) v0[q] /= l0[j];
+                    if (KIND == CS3_CHOLESKY && lane == k) v0[q] *= rdg;
                     const double xk = bcast_lane(v0[q], k);
                     if (lane > k) v0[q] -= l0[j] * xk;
                     v1[q] -= l1[j] * xk;
@@ -864,6 +873,7 @@ k_bwd_wave(const SolveDesc *__restrict__ sd, int first, int count, const int *__
         }
     }
     // back substitution with U11, columns w-1 .. 0
+    const double rdg = recip_diag(L, lane, r, lane < w);
     for (int k0 = w - 1; k0 >= 0; k0 -= SOLVE_PF) {
         double u[SOLVE_PF];
 #pragma unroll
@@ -879,7 +889,7 @@ k_bwd_wave(const SolveDesc *__restrict__ sd, int first, int count, const int *__
             if (k >= 0) {
 #pragma unroll
                 for (int q = 0; q < KT; ++q) {
-                    if (lane == k) v0[q] /= u[j];
+                    if (lane == k) v0[q] *= rdg;
                     const double xk = bcast_lane(v0[q], k);
                     if (lane < k) v0[q] -= u[j] * xk;
                 }
@@ -1118,10 +1128,11 @@ k_fwd_blk(const SolveDesc *__restrict__ sd, int first,
             for (int j = 0; j < SOLVE_BW; ++j)
                 lrow[j] = load_if(L, i + (long long) (kb + j) * r, j < bw && lane < bw && lane >= j);
             double vi = (lane < bw) ? v[i] : 0.0;
+            const double rdg = (KIND == CS3_CHOLESKY) ? recip_diag(L, i, r, lane < bw) : 1.0;
 #pragma unroll
             for (int j = 0; j < SOLVE_BW; ++j) {
                 if (j < bw) {
-                    if (KIND == CS3_CHOLESKY && lane == j) vi /= lrow[j];
+                    if (KIND == CS3_CHOLESKY && lane == j) vi *= rdg;
                     const double xk = bcast_lane(vi, j);
                     if (lane > j) vi -= lrow[j] * xk;
                 }
@@ -1191,11 +1202,12 @@ k_bwd_blk(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ s
                 urow[j] = load_if(L, off, j < bw && lane < bw && lane <= j);
             }
             double vi = (lane < bw) ? v[i] : 0.0;
+            const double rdg = recip_diag(L, i, r, lane < bw);
 #pragma unroll
             for (int jj = 0; jj < SOLVE_BW; ++jj) {
                 const int j = SOLVE_BW - 1 - jj;
                 if (j < bw) {
-                    if (lane == j) vi /= urow[j];
+                    if (lane == j) vi *= rdg;
                     const double xk = bcast_lane(vi, j);
                     if (lane < j) vi -= urow[j] * xk;
                 }
@@ -1244,84 +1256,128 @@ k_fwd_big_gather(const SolveDesc *__restrict__ sd, int first,
                  [&](int t, double val) { v[t] = val; });
 }
 
-// Triangle of chunk [kb, kb + bw) by wave 0: lane = row kb + lane.  lower: unit lower L (forward),
-// else upper U with its diagonal (backward).  y[] (LDS) receives the chunk's solution.
+// Triangle of a block [kb, kb + bw), bw <= 64, by one wave: lane = row kb + lane keeps its row of the
+// triangle in registers.  FORWARD: unit lower L (Cholesky: L with its diagonal), else upper U with its
+// diagonal (Cholesky: L').  Loading and solving are separate so that the loads of a second block
+// are in flight while the first is being solved.
 template <int KIND, bool FORWARD>
-__device__ __forceinline__ void big_triangle(const double *__restrict__ L, long long r, int kb, int bw,
-                                             const double *__restrict__ v, double *y)
-{
-    const int lane = threadIdx.x & 63;
-    const int i = kb + lane;
+struct BlockTriangle {
     double t[SOLVE_BW];
-#pragma unroll
-    for (int j = 0; j < SOLVE_BW; ++j) {
-        long long off;
-        bool need;
-        if (FORWARD) { off = (long long) i + (long long) (kb + j) * r; need = lane >= j; }
-        else {
-            off = (KIND == CS3_LU) ? (long long) i + (long long) (kb + j) * r : (long long) (kb + j) + (long long) i * r;
-            need = lane <= j;
-        }
-        t[j] = load_if(L, off, j < bw && lane < bw && need);
-    }
-    double vi = load_if(v, i, lane < bw);
-    if (FORWARD) {
+    double rdg;
+    __device__ __forceinline__ void load(const double *__restrict__ L, long long r, int kb, int bw)
+    {
+        const int lane = threadIdx.x & 63;
+        const int i = kb + lane;
 #pragma unroll
         for (int j = 0; j < SOLVE_BW; ++j) {
-            if (j < bw) {
-                if (KIND == CS3_CHOLESKY && lane == j) vi /= t[j];
-                const double xk = bcast_lane(vi, j);
-                if (lane > j) vi -= t[j] * xk;
+            long long off;
+            bool need;
+            if (FORWARD) { off = (long long) i + (long long) (kb + j) * r; need = lane >= j; }
+            else {
+                off = (KIND == CS3_LU) ? (long long) i + (long long) (kb + j) * r : (long long) (kb + j) + (long long) i * r;
+                need = lane <= j;
             }
+            t[j] = load_if(L, off, j < bw && lane < bw && need);
         }
-    } else {
-#pragma unroll
-        for (int jj = 0; jj < SOLVE_BW; ++jj) {
-            const int j = SOLVE_BW - 1 - jj;
-            if (j < bw) {
-                if (lane == j) vi /= t[j];
-                const double xk = bcast_lane(vi, j);
-                if (lane < j) vi -= t[j] * xk;
-            }
-        }
+        rdg = (!FORWARD || KIND == CS3_CHOLESKY) ? recip_diag(L, i, r, lane < bw) : 1.0;
     }
-    if (lane < bw) y[lane] = vi;
-}
+    __device__ __forceinline__ double solve(double vi, int bw) const
+    {
+        const int lane = threadIdx.x & 63;
+        if (FORWARD) {
+#pragma unroll
+            for (int j = 0; j < SOLVE_BW; ++j) {
+                if (j < bw) {
+                    if (KIND == CS3_CHOLESKY && lane == j) vi *= rdg;
+                    const double xk = bcast_lane(vi, j);
+                    if (lane > j) vi -= t[j] * xk;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < SOLVE_BW; ++jj) {
+                const int j = SOLVE_BW - 1 - jj;
+                if (j < bw) {
+                    if (lane == j) vi *= rdg;
+                    const double xk = bcast_lane(vi, j);
+                    if (lane < j) vi -= t[j] * xk;
+                }
+            }
+        }
+        return vi;
+    }
+};
 
-template <int KIND>
+// One launch per chunk of BIG_CW = 128 pivot columns = two blocks of 64.  Every workgroup solves the
+// chunk on its own: wave 0 the first block, wave 1 the second after taking the first block's
+// solution out of its rows (64 x 64, operands prefetched), then all four waves apply the chunk to
+// the workgroup's slice of 64 rows (4 threads per row, 32 columns each, prefetched before the
+// triangles; partial sums combined in a fixed order).
+// CW = 128 when the sweep is latency-bound (few right-hand sides: half the dependent launches),
+// CW = 64 when there are enough right-hand sides to fill the chip (no idle second block).
+constexpr int BIG_CW = 2 * SOLVE_BW;
+
+template <int KIND, int CW>
 __global__ void __launch_bounds__(256)
 k_fwd_big_step(const SolveDesc *__restrict__ sd, int first, int kb,
                const double *__restrict__ pool_all, double *__restrict__ cv_all, double *__restrict__ X_all,
                double *__restrict__ bigv_all, int nrhs, long long pool_stride, long long cv_stride,
                long long x_stride, long long bv_size)
 {
-    __shared__ double y[SOLVE_BW];
+    constexpr int SC = CW / 4;                      // chunk columns per wave in the slice update
+    __shared__ double y[BIG_CW];
     __shared__ double part[4][64];
     const SolveDesc d = sd[first + blockIdx.z];
     const int r = d.r, w = d.w;
     if (kb >= w) return;
-    const int bw = min(SOLVE_BW, w - kb), ke = kb + bw;
+    const int bw = min(CW, w - kb), ke = kb + bw;
+    const int bwa = min(SOLVE_BW, bw), bwb = bw - bwa;
     const int nsl = (r - ke + 63) / 64;
     if ((int) blockIdx.x > 0 && (int) blockIdx.x >= nsl) return;
     const int b = blockIdx.y / nrhs, rhs = blockIdx.y % nrhs;
     const double *L = pool_all + (long long) b * pool_stride + d.lpan;
     double *v = bigv_all + ((long long) b * nrhs + rhs) * bv_size + d.bv;
-    const int tid = threadIdx.x;
-    if (tid < 64) big_triangle<KIND, true>(L, r, kb, bw, v, y);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // my slice of rows below the chunk: wave wv takes columns [SC wv, SC wv + SC) of the chunk
+    const int row = ke + blockIdx.x * 64 + lane;
+    double ls[SC];
+#pragma unroll
+    for (int j = 0; j < SC; ++j) {
+        const int jj = wv * SC + j;
+        ls[j] = load_if(L, (long long) row + (long long) (kb + jj) * r, row < r && jj < bw);
+    }
+    if (wv == 0) {
+        BlockTriangle<KIND, true> ta;
+        ta.load(L, r, kb, bwa);
+        const double vi = ta.solve(load_if(v, kb + lane, lane < bwa), bwa);
+        if (lane < bwa) y[lane] = vi;
+        __syncthreads();
+    } else if (wv == 1 && bwb > 0) {
+        BlockTriangle<KIND, true> tb;
+        tb.load(L, r, kb + SOLVE_BW, bwb);
+        double tm[SOLVE_BW];                        // L(second block row, first block columns)
+#pragma unroll
+        for (int j = 0; j < SOLVE_BW; ++j)
+            tm[j] = load_if(L, (long long) (kb + SOLVE_BW + lane) + (long long) (kb + j) * r, lane < bwb);
+        double vi = load_if(v, kb + SOLVE_BW + lane, lane < bwb);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SOLVE_BW; ++j) vi -= tm[j] * y[j];
+        vi = tb.solve(vi, bwb);
+        if (lane < bwb) y[SOLVE_BW + lane] = vi;
+    } else {
+        __syncthreads();
+    }
     __syncthreads();
     if (blockIdx.x == 0 && tid < bw)
         X_all[(long long) b * x_stride + (long long) (d.c0 + kb + tid) * nrhs + rhs] = y[tid];
-    // my slice of rows below the chunk
-    const int row = ke + blockIdx.x * 64 + (tid & 63), quarter = tid >> 6;
     double acc = 0.0;
-    if (row < r) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int jj = quarter * 16 + j;
-            acc += load_if(L, (long long) row + (long long) (kb + jj) * r, jj < bw) * y[jj < bw ? jj : 0];
-        }
+    for (int j = 0; j < SC; ++j) {
+        const int jj = wv * SC + j;
+        acc += ls[j] * y[jj < bw ? jj : 0];          // ls[j] = 0 past the chunk
     }
-    part[quarter][tid & 63] = acc;
+    part[wv][lane] = acc;
     __syncthreads();
     if (tid < 64 && row < r) {
         const double nv = v[row] - (((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid]);
@@ -1370,42 +1426,74 @@ k_bwd_big_init(const SolveDesc *__restrict__ sd, int first, const int *__restric
     }
 }
 
-template <int KIND>
+template <int KIND, int CW>
 __global__ void __launch_bounds__(256)
 k_bwd_big_step(const SolveDesc *__restrict__ sd, int first, int chunk_from_right,
                const double *__restrict__ pool_all, double *__restrict__ X_all, double *__restrict__ bigv_all,
                int nrhs, long long pool_stride, long long x_stride, long long bv_size)
 {
-    __shared__ double y[SOLVE_BW];
+    constexpr int SC = CW / 4;
+    __shared__ double y[BIG_CW];
     __shared__ double part[4][64];
     const SolveDesc d = sd[first + blockIdx.z];
     const int r = d.r, w = d.w;
-    const int nchunk = (w + SOLVE_BW - 1) / SOLVE_BW;
+    const int nchunk = (w + CW - 1) / CW;
     const int c = nchunk - 1 - chunk_from_right;
     if (c < 0) return;
-    const int kb = c * SOLVE_BW, bw = min(SOLVE_BW, w - kb);
+    const int kb = c * CW, bw = min(CW, w - kb);
+    const int bwa = min(SOLVE_BW, bw), bwb = bw - bwa;     // blocks [kb, kb + bwa) and [kb + 64, kb + 64 + bwb)
     const int nsl = (kb + 63) / 64;                        // slices of rows above the chunk
     if ((int) blockIdx.x > 0 && (int) blockIdx.x >= nsl) return;
     const int b = blockIdx.y / nrhs, rhs = blockIdx.y % nrhs;
     const double *L = pool_all + (long long) b * pool_stride + d.lpan;
     double *v = bigv_all + ((long long) b * nrhs + rhs) * bv_size + d.bv;
-    const int tid = threadIdx.x;
-    if (tid < 64) big_triangle<KIND, false>(L, r, kb, bw, v, y);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int row = blockIdx.x * 64 + lane;
+    double us[SC];                                         // U(row, chunk columns [SC wv, SC wv + SC))
+#pragma unroll
+    for (int j = 0; j < SC; ++j) {
+        const int jj = wv * SC + j;
+        const long long off = (KIND == CS3_LU) ? (long long) row + (long long) (kb + jj) * r
+                                               : (long long) (kb + jj) + (long long) row * r;
+        us[j] = load_if(L, off, row < kb && jj < bw);
+    }
+    if (wv == 0) {                                         // right block first
+        if (bwb > 0) {
+            BlockTriangle<KIND, false> tb;
+            tb.load(L, r, kb + SOLVE_BW, bwb);
+            const double vi = tb.solve(load_if(v, kb + SOLVE_BW + lane, lane < bwb), bwb);
+            if (lane < bwb) y[SOLVE_BW + lane] = vi;
+        }
+        __syncthreads();
+    } else if (wv == 1) {
+        BlockTriangle<KIND, false> ta;
+        ta.load(L, r, kb, bwa);
+        double tm[SOLVE_BW];                               // U(left block row, right block columns)
+#pragma unroll
+        for (int j = 0; j < SOLVE_BW; ++j) {
+            const long long i = kb + lane, k = kb + SOLVE_BW + j;
+            const long long off = (KIND == CS3_LU) ? i + k * r : k + i * r;
+            tm[j] = load_if(L, off, lane < bwa && j < bwb);
+        }
+        double vi = load_if(v, kb + lane, lane < bwa);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SOLVE_BW; ++j) vi -= tm[j] * ((j < bwb) ? y[SOLVE_BW + j] : 0.0);
+        vi = ta.solve(vi, bwa);
+        if (lane < bwa) y[lane] = vi;
+    } else {
+        __syncthreads();
+    }
     __syncthreads();
     if (blockIdx.x == 0 && tid < bw)
         X_all[(long long) b * x_stride + (long long) (d.c0 + kb + tid) * nrhs + rhs] = y[tid];
-    const int row = blockIdx.x * 64 + (tid & 63), quarter = tid >> 6;
     double acc = 0.0;
-    if (row < kb) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int jj = quarter * 16 + j;
-            const long long off = (KIND == CS3_LU) ? (long long) row + (long long) (kb + jj) * r
-                                                   : (long long) (kb + jj) + (long long) row * r;
-            acc += load_if(L, off, jj < bw) * y[jj < bw ? jj : 0];
-        }
+    for (int j = 0; j < SC; ++j) {
+        const int jj = wv * SC + j;
+        acc += us[j] * y[jj < bw ? jj : 0];
     }
-    part[quarter][tid & 63] = acc;
+    part[wv][lane] = acc;
     __syncthreads();
     if (tid < 64 && row < kb)
         v[row] -= ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
@@ -1737,7 +1825,9 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
         }
     } else if (g.cls == SK_BIG) {
         const unsigned by = (unsigned) (D.batch * nrhs);
-        const int nchunk = (g.max_w + SOLVE_BW - 1) / SOLVE_BW;
+        const bool wide = (long long) D.batch * nrhs < 8;      // few right-hand sides: latency-bound, two blocks per launch
+        const int cw = wide ? BIG_CW : SOLVE_BW;
+        const int nchunk = (g.max_w + cw - 1) / cw;
         const int slices = std::max(1, (g.max_r + 63) / 64);
         if (forward) {
             // rows that no child updates have no source in the gather list: start from zero
@@ -1747,8 +1837,12 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
                                D.fasm_tgt, D.flong_src, D.cv, X, D.bigv, nrhs, cvs, xs, D.bv_size);
             CS3_LAUNCH_CHECK();
             for (int c = 0; c < nchunk; ++c) {
-                hipLaunchKernelGGL((k_fwd_big_step<KIND>), dim3(slices, by, g.count), dim3(256), 0, st, D.sdesc, g.first,
-                                   c * SOLVE_BW, D.pool, D.cv, X, D.bigv, nrhs, D.pool_size, cvs, xs, D.bv_size);
+                if (wide)
+                    hipLaunchKernelGGL((k_fwd_big_step<KIND, BIG_CW>), dim3(slices, by, g.count), dim3(256), 0, st, D.sdesc,
+                                       g.first, c * cw, D.pool, D.cv, X, D.bigv, nrhs, D.pool_size, cvs, xs, D.bv_size);
+                else
+                    hipLaunchKernelGGL((k_fwd_big_step<KIND, SOLVE_BW>), dim3(slices, by, g.count), dim3(256), 0, st, D.sdesc,
+                                       g.first, c * cw, D.pool, D.cv, X, D.bigv, nrhs, D.pool_size, cvs, xs, D.bv_size);
                 CS3_LAUNCH_CHECK();
             }
         } else {
@@ -1757,8 +1851,12 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
                                D.st_idx, D.pool, X, D.bigv, nrhs, D.pool_size, xs, D.bv_size);
             CS3_LAUNCH_CHECK();
             for (int c = 0; c < nchunk; ++c) {
-                hipLaunchKernelGGL((k_bwd_big_step<KIND>), dim3(slices, by, g.count), dim3(256), 0, st, D.sdesc, g.first,
-                                   c, D.pool, X, D.bigv, nrhs, D.pool_size, xs, D.bv_size);
+                if (wide)
+                    hipLaunchKernelGGL((k_bwd_big_step<KIND, BIG_CW>), dim3(slices, by, g.count), dim3(256), 0, st, D.sdesc,
+                                       g.first, c, D.pool, X, D.bigv, nrhs, D.pool_size, xs, D.bv_size);
+                else
+                    hipLaunchKernelGGL((k_bwd_big_step<KIND, SOLVE_BW>), dim3(slices, by, g.count), dim3(256), 0, st, D.sdesc,
+                                       g.first, c, D.pool, X, D.bigv, nrhs, D.pool_size, xs, D.bv_size);
                 CS3_LAUNCH_CHECK();
             }
         }
@@ -1834,7 +1932,7 @@ static int factor_group_cost(const LaunchGroup &g)
 }
 static int sweep_group_cost(const LaunchGroup &g)
 {
-    return (g.cls == SK_BIG) ? 2 + (g.max_w + SOLVE_BW - 1) / SOLVE_BW : 1;
+    return (g.cls == SK_BIG) ? 2 + (g.max_w + BIG_CW - 1) / BIG_CW : 1;
 }
 
 // Factorisation with the forward sweep partly hidden behind it.  The sweep of levels 0..K needs only

@@ -40,6 +40,17 @@ __device__ __forceinline__ double load_if(const double *__restrict__ p, long lon
     return ok ? v : 0.0;
 }
 
+// 1 / x on the critical path of every pivot: v_rcp_f64 and two Newton steps (about 1 ulp) instead of the
+// IEEE division sequence (div_scale / fmas / fixup, three times the dependent instructions).  A zero
+// or non-finite pivot still yields inf / nan, which the pivot checks reject.
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return y;
+}
+
 // 1 / diagonal entry `i` of an r-row panel: the sweeps multiply by it (one division per lane instead
 // of one per pivot step executed by the whole wave)
 __device__ __forceinline__ double recip_diag(const double *__restrict__ L, long long i, long long r, bool ok)
@@ -237,7 +248,7 @@ front_lds_body(const FrontDesc &d, int first, double *F,
         __syncthreads();
         const double piv = urow[k];
         const double dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
-        const double rdg = 1.0 / dg;               // one divide per pivot: multipliers are x * (1 / pivot)
+        const double rdg = fast_rcp(dg);           // one reciprocal per pivot: multipliers are x * (1 / pivot)
         if (ty == tyk) {                           // 2. column k / pivot -> lcol
 #pragma unroll
             for (int b = 0; b < RJ; ++b)
@@ -385,7 +396,7 @@ front_wave_body(const FrontDesc &d, int first, double *F,
                 const double piv = bcast_lane(row[kk], k);
                 const bool below = lane > k;
                 if (KIND == CS3_LU) {
-                    const double l = below ? row[kk] / piv : 0.0;   // multiplier, zero on and above the pivot row
+                    const double l = below ? row[kk] * fast_rcp(piv) : 0.0;   // multiplier, zero on and above the pivot row
                     if (below) row[kk] = l;
                     const bool rej = (live && !(fabs(l) <= inv_tol)) ||
                                      (lane == k && (!(fabs(piv) > 0.0) || !(fabs(piv) < 1.0e300)));
@@ -399,7 +410,7 @@ front_wave_body(const FrontDesc &d, int first, double *F,
                     }
                 } else {
                     const double dg = sqrt(piv);
-                    const double l = below ? row[kk] / dg : 0.0;
+                    const double l = below ? row[kk] * fast_rcp(dg) : 0.0;
                     if (below) row[kk] = l;
                     if (lane == k) {
                         row[kk] = (piv > 0.0) ? dg : -1.0;
@@ -491,46 +502,44 @@ k_big_gather(const FrontDesc *__restrict__ fdesc, int first,
                  [&](int t, double v) { pool[t] = v; });
 }
 
-// Unblocked LU / Cholesky of a bw x bw block (bw <= 32) held in LDS, by ONE wave and without
-// barriers: lane i keeps row i in 32 registers; for pivot k the pivot row is read lane-to-scalar
-// (v_readlane), so a step is (bw - k) scalar-operand FMAs plus one divide.  k is unrolled so that
-// every register index is static.
+// Unblocked LU / Cholesky of a 32 x 32 block by ONE wave without barriers, with a panel solve for
+// free: lanes 0..31 keep the rows of the block in 32 registers each, lanes 32..63 keep 32 rows of a
+// panel tile STACKED under it.  For pivot k the pivot row is read lane-to-scalar (v_readlane) and
+// every lane below it (all stacked lanes included) takes its multiplier and updates its row: when the
+// loop ends the stacked lanes hold  T U^-1  (LU; Cholesky: T L^-T), i.e. the solved panel rows --
+// the triangular solve that used to follow the factorisation costs nothing.
+//   * the block is identity-padded past its order, so the 32 steps run without a branch and the
+//     next pivot's reciprocal (v_rcp + two Newton steps) is issued right after the first column
+//     update of the current step, behind which its latency hides;
+//   * keep_unscaled (block-ROW tiles of LU): the block lanes hold D' and the stacked lanes columns of
+//     the tile; the multiplier t_k / u_kk drives the updates but the entry that is kept is t_k
+//     itself, which is U(k, column) for the unit-lower solve  L_D u = t.
 template <int KIND>
-__device__ __forceinline__ void factor_block32(double (*D)[BIG_NB + 1], int bw)
+__device__ __forceinline__ void eliminate32(double (&d)[BIG_NB], bool keep_unscaled)
 {
     const int lane = threadIdx.x & 63;
-    const int row = lane < bw ? lane : 0;
-    double d[BIG_NB];
-#pragma unroll
-    for (int j = 0; j < BIG_NB; ++j) d[j] = D[row][j];
+    const bool stacked = lane >= 32;
+    double piv = bcast_lane(d[0], 0);
+    double dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
+    double rp = fast_rcp(dg);
 #pragma unroll
     for (int k = 0; k < BIG_NB; ++k) {
-        if (k < bw) {                                   // wave-uniform
-            const double piv = bcast_lane(d[k], k);
-            if (KIND == CS3_LU) {
-                const double l = d[k] / piv;
-                if (lane > k) d[k] = l;
-#pragma unroll
-                for (int j = k + 1; j < BIG_NB; ++j) {
-                    const double u = bcast_lane(d[j], k);
-                    if (lane > k) d[j] -= l * u;
-                }
-            } else {
-                const double dg = sqrt(piv);
-                const double l = d[k] / dg;
-                if (lane > k) d[k] = l;
-                if (lane == k) d[k] = (piv > 0.0) ? dg : -1.0;
-#pragma unroll
-                for (int j = k + 1; j < BIG_NB; ++j) {
-                    const double lj = bcast_lane(d[k], j);      // L(j, k), already scaled (j > k)
-                    if (lane >= j) d[j] -= l * lj;
-                }
-            }
+        const bool below = lane > k;
+        const double l = below ? d[k] * rp : 0.0;
+        if (below && !(keep_unscaled && stacked)) d[k] = l;
+        if (KIND == CS3_CHOLESKY && lane == k) d[k] = (piv > 0.0) ? dg : -1.0;
+        if (k + 1 < BIG_NB) {
+            if (KIND == CS3_LU) d[k + 1] -= l * bcast_lane(d[k + 1], k);
+            else { const double lj = bcast_lane(d[k], k + 1); if (lane >= k + 1) d[k + 1] -= l * lj; }
+            piv = bcast_lane(d[k + 1], k + 1);
+            dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
+            rp = fast_rcp(dg);
         }
-    }
-    if (lane < bw) {
 #pragma unroll
-        for (int j = 0; j < BIG_NB; ++j) D[lane][j] = d[j];
+        for (int j = k + 2; j < BIG_NB; ++j) {
+            if (KIND == CS3_LU) d[j] -= l * bcast_lane(d[j], k);
+            else { const double lj = bcast_lane(d[k], j); if (lane >= j) d[j] -= l * lj; }      // L(j, k): lane j, register k
+        }
     }
 }
 
@@ -539,9 +548,10 @@ __device__ __forceinline__ void factor_block32(double (*D)[BIG_NB + 1], int bw)
 //   * every tile applies the update of the PREVIOUS panel  C -= L[:, kp:kb] U[kp:kb, :]
 //     (K = BIG_NB, operands written by the previous launch);
 //   * tiles on the new block column / block row also need the new diagonal block
-//     D = F[kb:ke, kb:ke] (updated the same way); each of them recomputes and factors
-//     it in LDS on its own (cheap, and it avoids any hand-off inside the launch), then
-//     solves its tile:  L[I, kb:ke] = C U_D^-1   or   U[kb:ke, J] = L_D^-1 C.
+//     D = F[kb:ke, kb:ke] (updated the same way); each of them recomputes it in LDS on its own
+//     (cheap, and it avoids any hand-off inside the launch) and eliminates it with its tile stacked
+//     underneath (eliminate32: waves 0 and 1 take 32 tile rows each), which yields
+//     L[I, kb:ke] = C U_D^-1   or   U[kb:ke, J] = L_D^-1 C   directly.
 // The factored D cannot be written into F during the launch (the other tiles read the
 // unfactored block), so tile (0,0) parks it in dbuf; the closing launch (kb >= w:
 // last update only) copies the parked blocks into place.
@@ -550,8 +560,12 @@ template <int KIND>
 __global__ void __launch_bounds__(256)
 k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__restrict__ pool_all,
            long long pool_stride, double *__restrict__ dbuf_all, long long dbuf_stride,
-           double inv_tol, int *status, int batch)
+           double inv_tol, int *status, int batch, long long *tbuf)
 {
+    // diagnostics (CS3_PROFILE=1): block-column tile (1, 0) of the step kb == 64 stamps its phases into the front's slot
+    const long long t_start = tbuf ? (long long) __builtin_amdgcn_s_memtime() : 0;
+#define CS3_BSTAMP(p) do { if (tbuf && kb == 64 && blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0) \
+        tbuf[(long long) (first + blockIdx.z / batch) * 8 + (p)] = (long long) __builtin_amdgcn_s_memtime() - t_start; } while (0)
     __shared__ double As[BIG_NB][64 + 1];       // As[k][i] = L(row0 + i, kp + k)
     __shared__ double Bs[BIG_NB][64 + 1];       // Bs[k][j] = U(kp + k, col0 + j)
     __shared__ double Ad[BIG_NB][BIG_NB + 1];   // Ad[k][i] = L(kb + i, kp + k)
@@ -591,42 +605,25 @@ k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__res
     const bool needs_d = has_panel && (bi == 0 || bj == 0);
     const int tx = tid % 16, ty = tid / 16;
 
-    // ---- stage the previous panel's operands (and D's) in LDS
+    // ---- every global load of this tile goes out before the first LDS store: one round trip
+    double ra[8], rb[8], rad[4], rbd[4];
     if (kb > 0) {
-        for (int e = tid; e < BIG_NB * 64; e += 256) {
-            const int i = e % 64, k = e / 64;
-            As[k][i] = load_if(F, (row0 + i) + (long long) (kp + k) * ld, k < pw && i < nrow);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + 256 * q;
+            { const int i = e % 64, k = e / 64; ra[q] = load_if(F, (row0 + i) + (long long) (kp + k) * ld, k < pw && i < nrow); }
+            if (KIND == CS3_LU) { const int k = e % BIG_NB, j = e / BIG_NB; rb[q] = load_if(F, (kp + k) + (long long) (col0 + j) * ld, k < pw && j < ncol); }
+            else { const int j = e % 64, k = e / 64; rb[q] = load_if(F, (col0 + j) + (long long) (kp + k) * ld, k < pw && j < ncol); }
         }
-        if (KIND == CS3_LU) {
-            for (int e = tid; e < BIG_NB * 64; e += 256) {
-                const int k = e % BIG_NB, j = e / BIG_NB;
-                Bs[k][j] = load_if(F, (kp + k) + (long long) (col0 + j) * ld, k < pw && j < ncol);
-            }
-        } else {
-            for (int e = tid; e < BIG_NB * 64; e += 256) {
-                const int j = e % 64, k = e / 64;
-                Bs[k][j] = load_if(F, (col0 + j) + (long long) (kp + k) * ld, k < pw && j < ncol);
-            }
-        }
-        if (needs_d) {
-            for (int e = tid; e < BIG_NB * BIG_NB; e += 256) {
-                const int i = e % BIG_NB, k = e / BIG_NB;
-                Ad[k][i] = load_if(F, (kb + i) + (long long) (kp + k) * ld, k < pw && i < bw);
-            }
-            if (KIND == CS3_LU) {
-                for (int e = tid; e < BIG_NB * BIG_NB; e += 256) {
-                    const int k = e % BIG_NB, j = e / BIG_NB;
-                    Bd[k][j] = load_if(F, (kp + k) + (long long) (kb + j) * ld, k < pw && j < bw);
-                }
-            } else {
-                for (int e = tid; e < BIG_NB * BIG_NB; e += 256) {
-                    const int j = e % BIG_NB, k = e / BIG_NB;
-                    Bd[k][j] = load_if(F, (kb + j) + (long long) (kp + k) * ld, k < pw && j < bw);
-                }
-            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q;
+            { const int i = e % BIG_NB, k = e / BIG_NB; rad[q] = load_if(F, (kb + i) + (long long) (kp + k) * ld, needs_d && k < pw && i < bw); }
+            if (KIND == CS3_LU) { const int k = e % BIG_NB, j = e / BIG_NB; rbd[q] = load_if(F, (kp + k) + (long long) (kb + j) * ld, needs_d && k < pw && j < bw); }
+            else { const int j = e % BIG_NB, k = e / BIG_NB; rbd[q] = load_if(F, (kb + j) + (long long) (kp + k) * ld, needs_d && k < pw && j < bw); }
         }
     }
-    // my 4 x 4 outputs and D's 4 entries, loaded while the staging loads are in flight
+    // my 4 x 4 outputs and D's 4 entries
     double acc[4][4];
 #pragma unroll
     for (int v = 0; v < 4; ++v)
@@ -640,7 +637,25 @@ k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__res
 #pragma unroll
     for (int c = 0; c < 4; ++c)
         dacc[c] = load_if(F, (kb + di) + (long long) (kb + dj + 8 * c) * ld, needs_d && di < bw && dj + 8 * c < bw);
+    CS3_BSTAMP(0);
+    if (kb > 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + 256 * q;
+            As[e / 64][e % 64] = ra[q];
+            if (KIND == CS3_LU) Bs[e % BIG_NB][e / BIG_NB] = rb[q]; else Bs[e / 64][e % 64] = rb[q];
+        }
+        if (needs_d) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = tid + 256 * q;
+                Ad[e / BIG_NB][e % BIG_NB] = rad[q];
+                if (KIND == CS3_LU) Bd[e % BIG_NB][e / BIG_NB] = rbd[q]; else Bd[e / BIG_NB][e % BIG_NB] = rbd[q];
+            }
+        }
+    }
     __syncthreads();
+    CS3_BSTAMP(1);
     if (kb > 0) {
 #pragma unroll 8
         for (int k = 0; k < BIG_NB; ++k) {
@@ -672,10 +687,14 @@ k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__res
             }
         return;
     }
+    CS3_BSTAMP(2);
 
-    // ---- factor D in LDS
+    // ---- the updated D (identity-padded past bw) and my tile meet in LDS
 #pragma unroll
-    for (int c = 0; c < 4; ++c) D[di][dj + 8 * c] = dacc[c];
+    for (int c = 0; c < 4; ++c) {
+        const int j = dj + 8 * c;
+        D[di][j] = (di < bw && j < bw) ? dacc[c] : (di == j ? 1.0 : 0.0);
+    }
     if (bi > 0) {                                   // block-column tile: T[row][col]
 #pragma unroll
         for (int v = 0; v < 2; ++v)
@@ -688,57 +707,61 @@ k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__res
             for (int u = 0; u < 2; ++u) T[ty + 16 * v][tx + 16 * u] = acc[u][v];
     }
     __syncthreads();
-    if (tid < 64) factor_block32<KIND>(D, bw);      // wave 0: lane = row, the row lives in registers
-    __syncthreads();
-    if (bi == 0 && bj == 0) {                       // park the factored block, check its pivots
+    CS3_BSTAMP(3);
+    if (tid >= 128) return;                         // waves 0 and 1 carry on: 32 stacked tile rows each
+    const int lane = tid & 63, half = tid >> 6, li = lane & 31;
+    const bool stacked = lane >= 32;
+    const bool row_tile = (bi == 0 && bj > 0);      // block-row tile (LU only): eliminate D' with tile columns stacked
+    const bool diag_tile = (bi == 0 && bj == 0);
+    if (diag_tile && half == 1) return;
+    double e[BIG_NB];
+#pragma unroll
+    for (int j = 0; j < BIG_NB; ++j) {
+        const double dv = row_tile ? D[j][li] : D[li][j];
+        const double tv = T[32 * half + li][j];
+        e[j] = stacked ? (diag_tile ? 0.0 : tv) : dv;
+    }
+    eliminate32<KIND>(e, row_tile);
+    CS3_BSTAMP(4);
+    if (diag_tile) {                                // park the factored block, check its pivots
         double *db = dbuf + (long long) (kb / BIG_NB) * (BIG_NB * BIG_NB);
-        for (int e = tid; e < bw * bw; e += 256) {
-            const int i = e % bw, j = e / bw;
-            const double v = D[i][j];
-            if (KIND == CS3_LU) {
-                if (i > j) { if (!(fabs(v) <= inv_tol)) flag_column(status, d.c0 + kb + j); }
-                else if (i == j) { if (!(fabs(v) > 0.0) || !(fabs(v) < 1.0e300)) flag_column(status, d.c0 + kb + j); }
-            } else if (i == j) {
-                if (!(v > 0.0)) flag_column(status, d.c0 + kb + j);
+        if (lane < bw) {
+#pragma unroll
+            for (int j = 0; j < BIG_NB; ++j) {
+                if (j < bw) {
+                    const double v = e[j];
+                    if (KIND == CS3_LU) {
+                        if (lane > j) { if (!(fabs(v) <= inv_tol)) flag_column(status, d.c0 + kb + j); }
+                        else if (lane == j) { if (!(fabs(v) > 0.0) || !(fabs(v) < 1.0e300)) flag_column(status, d.c0 + kb + j); }
+                    } else if (lane == j) {
+                        if (!(v > 0.0)) flag_column(status, d.c0 + kb + j);
+                    }
+                    db[lane + j * BIG_NB] = v;
+                }
             }
-            db[i + j * BIG_NB] = v;
         }
         return;
     }
-    // right-looking triangular solves: once x_c is known it is applied to every later column, so the
-    // FMAs of one step are independent of each other (no 32-deep dependent chain per row)
-    if (bi > 0) {
-        if (tid < 64 && tid < nrow) {              // x U_D = t  (Cholesky: x L_D' = t), one row per lane
-            double t[BIG_NB];
+    const int tr = 32 * half + li;                  // my row (block-column tile) or column (block-row tile) of the tile
+    if (stacked) {
+        if (!row_tile) {
+            if (tr < nrow) {
 #pragma unroll
-            for (int c = 0; c < BIG_NB; ++c) t[c] = T[tid][c];
-#pragma unroll
-            for (int c = 0; c < BIG_NB; ++c) {
-                if (c < bw) {
-                    const double x = t[c] / D[c][c];
-                    if (KIND == CS3_LU && !(fabs(x) <= inv_tol)) flag_column(status, d.c0 + kb + c);
-                    F[(row0 + tid) + (long long) (kb + c) * ld] = x;
-#pragma unroll
-                    for (int j = c + 1; j < BIG_NB; ++j) t[j] -= x * ((KIND == CS3_LU) ? D[c][j] : D[j][c]);
+                for (int c = 0; c < BIG_NB; ++c) {
+                    if (c < bw) {
+                        if (KIND == CS3_LU && !(fabs(e[c]) <= inv_tol)) flag_column(status, d.c0 + kb + c);
+                        F[(row0 + tr) + (long long) (kb + c) * ld] = e[c];
+                    }
                 }
             }
-        }
-    } else {
-        if (tid < 64 && tid < ncol) {              // L_D u = t, L_D unit lower, one column per lane
-            double t[BIG_NB];
+        } else if (tr < ncol) {
 #pragma unroll
-            for (int c = 0; c < BIG_NB; ++c) t[c] = T[tid][c];
-#pragma unroll
-            for (int c = 0; c < BIG_NB; ++c) {
-                if (c < bw) {
-                    const double u = t[c];
-                    F[(kb + c) + (long long) (col0 + tid) * ld] = u;
-#pragma unroll
-                    for (int j = c + 1; j < BIG_NB; ++j) t[j] -= D[j][c] * u;
-                }
-            }
+            for (int c = 0; c < BIG_NB; ++c)
+                if (c < bw) F[(kb + c) + (long long) (col0 + tr) * ld] = e[c];
         }
     }
+    CS3_BSTAMP(5);
+#undef CS3_BSTAMP
 }
 
 
@@ -1650,7 +1673,7 @@ static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g
             const int rem = g.max_r - std::min(start, g.max_r);        // largest trailing order over the group
             const int tiles = 1 + (rem + 63) / 64;
             hipLaunchKernelGGL((k_big_step<KIND>), dim3(tiles, tiles, g.count * batch), dim3(256), 0, st, D.fdesc,
-                               g.first, kb, D.pool, D.pool_size, D.dbuf, D.dbuf_size, inv_tol, D.status, (int) batch);
+                               g.first, kb, D.pool, D.pool_size, D.dbuf, D.dbuf_size, inv_tol, D.status, (int) batch, D.tbuf);
             CS3_LAUNCH_CHECK();
         }
         return hipSuccess;

@@ -34,3 +34,8 @@ for l in range(int(lvl.max()) + 1):
     if msk.sum():
         j = np.flatnonzero(msk)[np.argmax(out[msk, 5])]
         print("level", l, "fronts", msk.sum(), "slowest: r,w =", fr[j], fw[j], "phases", d[j, :6])
+# blocked big fronts: phases of the block-column tile (1, 0) in the step kb = 64
+big = np.flatnonzero((fr > 136) & (out[:, 5] > 0))
+for j in big:
+    print("big front r,w =", fr[j], fw[j], "step kb=64 tile(1,0) cycles since kernel start: loads issued %d, staged %d, updated %d, "
+          "D/T in LDS %d, D factored %d, panel solved+stored %d" % tuple(out[j, :6]))

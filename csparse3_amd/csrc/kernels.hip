@@ -304,7 +304,7 @@ front_lds_body(const FrontDesc &d, int first, double *F,
             if (j < w) {
                 if (KIND == CS3_LU || i >= j) L[i + (long long) j * r] = v;
             } else if (i < w) {
-                if (KIND == CS3_LU) U[(j - w) + (long long) i * nb] = v;
+                if (KIND == CS3_LU) U[(long long) (j - w) * d.u_sj + (long long) i * d.u_sk] = v;
             } else if (has_parent) {
                 if (KIND == CS3_LU || i >= j) cb[(i - w) + (long long) (j - w) * nb] = v;
             }
@@ -340,7 +340,6 @@ front_wave_body(const FrontDesc &d, int first, double *F,
                 const double *__restrict__ ax_all, double *__restrict__ pool_all,
                 long long nnz_a, long long pool_stride, double inv_tol, int *status, long long *tbuf, long long t_start)
 {
-    constexpr int PB = 8;
 #define CS3_STAMP(p) do { if (tbuf && threadIdx.x == 0) tbuf[(long long) (first + blockIdx.x) * 8 + (p)] = (long long) __builtin_amdgcn_s_memtime() - t_start; } while (0)
     const double *ax = ax_all + (long long) blockIdx.y * nnz_a;
     double *pool = pool_all + (long long) blockIdx.y * pool_stride;
@@ -369,75 +368,73 @@ front_wave_body(const FrontDesc &d, int first, double *F,
             row[j] = (lane < r && j < r) ? v : 0.0;
         }
     }
-    double *L = pool + d.lpan;
-    double *U = pool + d.upan;
-    double *cb = pool + d.cb;
     const bool has_parent = d.parent >= 0;
     const bool live = lane < r;
-    // where my entry of column `col` goes: panel, U panel or contribution block (one predicated store)
-    auto put = [&](int col, double v) {
-        const bool in_l = col < w, in_u = !in_l && lane < w;
-        double *dst = in_l ? L + (lane + (long long) col * r)
-                           : in_u ? U + ((col - w) + (long long) lane * nb)
-                                  : cb + ((lane - w) + (long long) (col - w) * nb);
-        bool ok = live && col < r && (in_l || in_u || has_parent);
-        if (KIND == CS3_CHOLESKY) ok = ok && !in_u && lane >= col;
-        if (ok) *dst = v;
-    };
     bool bad = false;
     int bad_col = 0;
-    int kb = 0;
     CS3_STAMP(3);
-    for (; kb < w; kb += PB) {
+    // Elimination only: column k of the registers is column k of the front for the whole loop (no
+    // stores, no checks, no shifting inside it); the reciprocal of the next pivot is issued right
+    // after the first column update of a step, behind which its latency hides.
+    {
+        double piv = bcast_lane(row[0], 0);
+        double dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
+        double rp = fast_rcp(dg);
 #pragma unroll
-        for (int kk = 0; kk < PB; ++kk) {
-            const int k = kb + kk;
+        for (int k = 0; k < NC; ++k) {
             if (k < w) {                                        // wave-uniform
-                const double piv = bcast_lane(row[kk], k);
                 const bool below = lane > k;
-                if (KIND == CS3_LU) {
-                    const double l = below ? row[kk] * fast_rcp(piv) : 0.0;   // multiplier, zero on and above the pivot row
-                    if (below) row[kk] = l;
-                    const bool rej = (live && !(fabs(l) <= inv_tol)) ||
-                                     (lane == k && (!(fabs(piv) > 0.0) || !(fabs(piv) < 1.0e300)));
-                    if (rej && !bad) { bad = true; bad_col = k; }
+                const double l = below ? row[k] * rp : 0.0;     // multiplier, zero on and above the pivot row
+                if (below) row[k] = l;
+                if (KIND == CS3_CHOLESKY && lane == k) row[k] = (piv > 0.0) ? dg : -1.0;
+                if (k + 1 < NC) {
+                    if (KIND == CS3_LU) row[k + 1] -= l * bcast_lane(row[k + 1], k);
+                    else { const double lj = bcast_lane(row[k], k + 1); row[k + 1] -= (lane >= k + 1 ? l : 0.0) * lj; }
+                    piv = bcast_lane(row[k + 1], k + 1);
+                    dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
+                    rp = fast_rcp(dg);
+                }
 #pragma unroll
-                    for (int j0 = kk + 1; j0 < NC; j0 += 8) {
-                        if (kb + j0 < r) {                      // skip register groups beyond the front
+                for (int j0 = (k + 2) & ~7; j0 < NC; j0 += 8) {
+                    if (j0 < r) {                               // skip register groups beyond the front
 #pragma unroll
-                            for (int j = j0; j < j0 + 8 && j < NC; ++j) row[j] -= l * bcast_lane(row[j], k);
-                        }
-                    }
-                } else {
-                    const double dg = sqrt(piv);
-                    const double l = below ? row[kk] * fast_rcp(dg) : 0.0;
-                    if (below) row[kk] = l;
-                    if (lane == k) {
-                        row[kk] = (piv > 0.0) ? dg : -1.0;
-                        if (!(piv > 0.0) && !bad) { bad = true; bad_col = k; }
-                    }
-#pragma unroll
-                    for (int j0 = kk + 1; j0 < NC; j0 += 8) {
-                        if (kb + j0 < r) {
-#pragma unroll
-                            for (int j = j0; j < j0 + 8 && j < NC; ++j) {
-                                const int col = min(kb + j, 63);
-                                const double lj = bcast_lane(row[kk], col);   // L(col, k): lane col, same register
-                                row[j] -= (lane >= kb + j ? l : 0.0) * lj;
-                            }
+                        for (int j = (j0 > k + 2 ? j0 : k + 2); j < j0 + 8; ++j) {
+                            if (KIND == CS3_LU) row[j] -= l * bcast_lane(row[j], k);
+                            else { const double lj = bcast_lane(row[k], j); row[j] -= (lane >= j ? l : 0.0) * lj; }
                         }
                     }
                 }
             }
         }
-#pragma unroll
-        for (int kk = 0; kk < PB; ++kk) put(kb + kk, row[kk]);
-#pragma unroll
-        for (int j = 0; j < NC; ++j) row[j] = (j + PB < NC) ? row[j + PB] : 0.0;
     }
     CS3_STAMP(4);
+    // checks and stores, one pass.  Pool offsets fit 32 bits (analysis refuses larger pools): column j of
+    // my row goes to the L panel (j < w), else to the U panel (my row is a pivot row) or the contribution block.
+    {
+        const int lp = (int) d.lpan + lane;
+        const int base2 = (lane < w) ? (int) d.upan + lane * d.u_sk - w * d.u_sj : (int) d.cb + (lane - w) - w * nb;
+        const int stride2 = (lane < w) ? d.u_sj : nb;
+        const bool ok2 = live && ((lane < w) ? (KIND == CS3_LU) : has_parent);
 #pragma unroll
-    for (int j = 0; j < NC; ++j) put(kb + j, row[j]);
+        for (int j = 0; j < NC; ++j) {
+            if (j < r) {                                        // wave-uniform
+                const double v = row[j];
+                const bool tri = (KIND == CS3_LU) || lane >= j;     // Cholesky keeps the lower triangle only
+                if (j < w) {
+                    bool rej;
+                    if (KIND == CS3_LU)
+                        rej = (live && lane > j && !(fabs(v) <= inv_tol)) ||
+                              (lane == j && (!(fabs(v) > 0.0) || !(fabs(v) < 1.0e300)));
+                    else
+                        rej = (lane == j && !(v > 0.0));
+                    if (rej && !bad) { bad = true; bad_col = j; }
+                    if (live && tri) pool[lp + j * r] = v;
+                } else if (ok2 && tri) {
+                    pool[base2 + j * stride2] = v;
+                }
+            }
+        }
+    }
     if (bad) flag_column(status, d.c0 + bad_col);
     CS3_STAMP(5);
 #undef CS3_STAMP

@@ -403,7 +403,8 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         }
         if (S.sn_class[s] == FC_BIG) continue;
         S.lpan_off[s] = voff; voff += r * w;
-        if (kind == CS3_LU) { S.upan_off[s] = voff; voff += nb * w; S.u_sk[s] = (i32) nb; S.u_sj[s] = 1; }
+        // U panel w x nb, pivot rows contiguous: a wave whose lanes are rows stores and reads it coalesced
+        if (kind == CS3_LU) { S.upan_off[s] = voff; voff += nb * w; S.u_sk[s] = 1; S.u_sj[s] = (i32) w; }
     }
     S.big_begin = voff;
     for (i32 s = 0; s < ns; ++s) {                   // dense buffers of the big fronts

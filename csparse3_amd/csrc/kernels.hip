@@ -25,6 +25,8 @@
 
 namespace cs3 {
 
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
 // ----------------------------------------------------- assembly by gather --
 // A front's assembly list holds (target, source) pairs sorted by target; runs
 // of equal targets never cross a 64-entry boundary, so one wave owns whole
@@ -414,24 +416,28 @@ front_wave_body(const FrontDesc &d, int first, double *F,
         const int lp = (int) d.lpan + lane;
         const int base2 = (lane < w) ? (int) d.upan + lane * d.u_sk - w * d.u_sj : (int) d.cb + (lane - w) - w * nb;
         const int stride2 = (lane < w) ? d.u_sj : nb;
-        const bool ok2 = live && ((lane < w) ? (KIND == CS3_LU) : has_parent);
+        const bool ok2 = live & ((lane < w) ? (KIND == CS3_LU) : has_parent);
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
             if (j < r) {                                        // wave-uniform
                 const double v = row[j];
-                const bool tri = (KIND == CS3_LU) || lane >= j;     // Cholesky keeps the lower triangle only
-                if (j < w) {
-                    bool rej;
-                    if (KIND == CS3_LU)
-                        rej = (live && lane > j && !(fabs(v) <= inv_tol)) ||
-                              (lane == j && (!(fabs(v) > 0.0) || !(fabs(v) < 1.0e300)));
-                    else
-                        rej = (lane == j && !(v > 0.0));
-                    if (rej && !bad) { bad = true; bad_col = j; }
-                    if (live && tri) pool[lp + j * r] = v;
-                } else if (ok2 && tri) {
-                    pool[base2 + j * stride2] = v;
+                const double av = fabs(v);
+                const bool tri = (KIND == CS3_LU) | (lane >= j);    // Cholesky keeps the lower triangle only
+                const bool in_l = j < w;                            // wave-uniform
+                // mask logic, no short-circuit branches: multipliers |l| <= 1/tol, pivot non-zero and finite
+                bool rej;
+                if (KIND == CS3_LU) {
+                    const double lim = (lane == j) ? 1.0e300 : inv_tol;
+                    rej = (live & (lane >= j) & !(av <= lim)) | ((lane == j) & !(av > 0.0));
+                } else {
+                    rej = (lane == j) & !(v > 0.0);
                 }
+                rej = rej & in_l;
+                bad_col = (rej & !bad) ? j : bad_col;
+                bad = bad | rej;
+                const int off = in_l ? lp + j * r : base2 + j * stride2;
+                const bool ok = (in_l ? live : ok2) & tri;
+                if (ok) pool[off] = v;
             }
         }
     }
@@ -600,7 +606,6 @@ k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__res
     const int row0 = (bi == 0) ? kb : ke + (bi - 1) * 64, nrow = (bi == 0) ? bw : min(64, r - row0);
     const int col0 = (bj == 0) ? kb : ke + (bj - 1) * 64, ncol = (bj == 0) ? bw : min(64, r - col0);
     const bool needs_d = has_panel && (bi == 0 || bj == 0);
-    const int tx = tid % 16, ty = tid / 16;
 
     // ---- every global load of this tile goes out before the first LDS store: one round trip
     double ra[8], rb[8], rad[4], rbd[4];
@@ -620,33 +625,38 @@ k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__res
             else { const int j = e % BIG_NB, k = e / BIG_NB; rbd[q] = load_if(F, (kb + j) + (long long) (kp + k) * ld, needs_d && k < pw && j < bw); }
         }
     }
-    // my 4 x 4 outputs and D's 4 entries
-    double acc[4][4];
+    // my outputs, in the register layout of v_mfma_f64_16x16x4 with the tile transposed (A operand = U
+    // panel, B operand = L panel, so that lanes % 16 run along tile ROWS and global accesses stay
+    // coalesced): wave wv owns tile rows [16 wv, 16 wv + 16), acc[cb][v] = F(row0 + 16 wv + mi, col0 + 16 cb + mq + 4 v)
+    const int wv = tid >> 6, mi = tid & 15, mq = (tid >> 4) & 3;
+    const int ti = 16 * wv + mi;
+    double4_t acc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int j = 16 * cb + mq + 4 * v;
+            acc[cb][v] = load_if(F, (row0 + ti) + (long long) (col0 + j) * ld, ti < nrow && j < ncol);
+        }
+    // D, same scheme: wave wv owns the 16 x 16 sub-block (wv & 1, wv >> 1): dacc[v] = D(dr, dc0 + 4 v)
+    const int dr = 16 * (wv & 1) + mi, dc0 = 16 * (wv >> 1) + mq;
+    double4_t dacc;
 #pragma unroll
     for (int v = 0; v < 4; ++v)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = tx + 16 * u, j = ty + 16 * v;
-            acc[u][v] = load_if(F, (row0 + i) + (long long) (col0 + j) * ld, i < nrow && j < ncol);
-        }
-    const int di = tid & 31, dj = tid >> 5;                    // D entries (di, dj + 8c)
-    double dacc[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-        dacc[c] = load_if(F, (kb + di) + (long long) (kb + dj + 8 * c) * ld, needs_d && di < bw && dj + 8 * c < bw);
+        dacc[v] = load_if(F, (kb + dr) + (long long) (kb + dc0 + 4 * v) * ld, needs_d && dr < bw && dc0 + 4 * v < bw);
     CS3_BSTAMP(0);
     if (kb > 0) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int e = tid + 256 * q;
-            As[e / 64][e % 64] = ra[q];
+            As[e / 64][e % 64] = -ra[q];                  // negated: the MFMA accumulates acc += U' (-L)'
             if (KIND == CS3_LU) Bs[e % BIG_NB][e / BIG_NB] = rb[q]; else Bs[e / 64][e % 64] = rb[q];
         }
         if (needs_d) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int e = tid + 256 * q;
-                Ad[e / BIG_NB][e % BIG_NB] = rad[q];
+                Ad[e / BIG_NB][e % BIG_NB] = -rad[q];
                 if (KIND == CS3_LU) Bd[e % BIG_NB][e / BIG_NB] = rbd[q]; else Bd[e / BIG_NB][e % BIG_NB] = rbd[q];
             }
         }
@@ -654,33 +664,27 @@ k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__res
     __syncthreads();
     CS3_BSTAMP(1);
     if (kb > 0) {
-#pragma unroll 8
-        for (int k = 0; k < BIG_NB; ++k) {
-            double a[4], b[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { a[u] = As[k][tx + 16 * u]; b[u] = Bs[k][ty + 16 * u]; }
+        for (int k0 = 0; k0 < BIG_NB; k0 += 4) {
+            const double bl = As[k0 + mq][ti];                  // B operand: -L(row ti, k0 + mq), lane mi + 16 mq
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) acc[u][v] -= a[u] * b[v];
+            for (int cb = 0; cb < 4; ++cb)                      // A operand: U(k0 + mq, column 16 cb + mi)
+                acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bs[k0 + mq][16 * cb + mi], bl, acc[cb], 0, 0, 0);
         }
         if (needs_d) {
-#pragma unroll 8
-            for (int k = 0; k < BIG_NB; ++k) {
-                const double a = Ad[k][di];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) dacc[c] -= a * Bd[k][dj + 8 * c];
-            }
+            for (int k0 = 0; k0 < BIG_NB; k0 += 4)
+                dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(Bd[k0 + mq][16 * (wv >> 1) + mi], Ad[k0 + mq][dr], dacc, 0, 0, 0);
         }
     }
     if (!needs_d) {                                 // plain trailing tile: store and leave
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
+        for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = tx + 16 * u, j = ty + 16 * v;
-                if (i < nrow && j < ncol && (KIND == CS3_LU || row0 + i >= col0 + j))
-                    F[(row0 + i) + (long long) (col0 + j) * ld] = acc[u][v];
+            for (int v = 0; v < 4; ++v) {
+                const int j = 16 * cb + mq + 4 * v;
+                if (ti < nrow && j < ncol && (KIND == CS3_LU || row0 + ti >= col0 + j))
+                    F[(row0 + ti) + (long long) (col0 + j) * ld] = acc[cb][v];
             }
         return;
     }
@@ -688,20 +692,20 @@ k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__res
 
     // ---- the updated D (identity-padded past bw) and my tile meet in LDS
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int j = dj + 8 * c;
-        D[di][j] = (di < bw && j < bw) ? dacc[c] : (di == j ? 1.0 : 0.0);
+    for (int v = 0; v < 4; ++v) {
+        const int j = dc0 + 4 * v;
+        D[dr][j] = (dr < bw && j < bw) ? dacc[v] : (dr == j ? 1.0 : 0.0);
     }
-    if (bi > 0) {                                   // block-column tile: T[row][col]
+    if (bi > 0) {                                   // block-column tile: T[row][col], 32 columns
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
+        for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) T[tx + 16 * u][ty + 16 * v] = acc[u][v];
-    } else if (bj > 0) {                            // block-row tile: T[col][row]
+            for (int v = 0; v < 4; ++v) T[ti][16 * cb + mq + 4 * v] = acc[cb][v];
+    } else if (bj > 0 && wv < 2) {                  // block-row tile: T[col][row], 32 rows
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
+        for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) T[ty + 16 * v][tx + 16 * u] = acc[u][v];
+            for (int v = 0; v < 4; ++v) T[16 * cb + mq + 4 * v][ti] = acc[cb][v];
     }
     __syncthreads();
     CS3_BSTAMP(3);

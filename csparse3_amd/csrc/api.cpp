@@ -178,9 +178,7 @@ int run_factor(cs3_handle h, const double *ax_dev, double tol, hipStream_t st)
 {
     DeviceFactor &D = h->D;
     const double inv_tol = (tol > 0.0) ? 1.0 / tol : HUGE_VAL;
-    CS3_HIP(hipMemsetAsync(D.status, 0x7f, sizeof(int), st));   // 0x7f7f7f7f = clean
-    if (ax_dev != D.ax && D.nnz_a > 0)
-        CS3_HIP(hipMemcpyAsync(D.ax, ax_dev, (size_t) (D.batch * D.nnz_a) * sizeof(double), hipMemcpyDeviceToDevice, st));
+    CS3_HIP(launch_prologue(D, ax_dev, nullptr, 0, st));        // status 0x7f7f7f7f = clean, zeros, values
     if (h->use_graph) {
         if (h->factor_graph && h->factor_graph_inv_tol != inv_tol) {
             (void) hipGraphExecDestroy(h->factor_graph);
@@ -262,10 +260,7 @@ int run_factor_solve(cs3_handle h, const double *ax_dev, double *x_dev, long lon
     DeviceFactor &D = h->D;
     const int nrhs = (int) k;
     const double inv_tol = (tol > 0.0) ? 1.0 / tol : HUGE_VAL;
-    CS3_HIP(hipMemsetAsync(D.status, 0x7f, sizeof(int), st));
-    if (ax_dev != D.ax && D.nnz_a > 0)
-        CS3_HIP(hipMemcpyAsync(D.ax, ax_dev, (size_t) (D.batch * D.nnz_a) * sizeof(double), hipMemcpyDeviceToDevice, st));
-    CS3_HIP(launch_permute(D, x_dev, D.xp, nrhs, false, st));
+    CS3_HIP(launch_prologue(D, ax_dev, x_dev, nrhs, st));
     if (h->use_graph) {
         if (h->fused_inv_tol != inv_tol) {
             for (auto &kv : h->fused_graphs) (void) hipGraphExecDestroy(kv.second);

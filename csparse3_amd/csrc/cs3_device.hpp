@@ -86,6 +86,8 @@ hipError_t launch_solve_levels(const DeviceFactor &D, const std::vector<LaunchGr
 hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<LaunchGroup> &fgroups,
                                       const std::vector<LaunchGroup> &sgroups, double inv_tol, double *X, int nrhs,
                                       hipStream_t st, ForkJoin &fj);
+// status word, big-front zeros, copy of the caller's values and (x_src != null) the permuted right-hand sides, one launch
+hipError_t launch_prologue(const DeviceFactor &D, const double *ax_src, const double *x_src, int nrhs, hipStream_t st);
 hipError_t launch_permute(const DeviceFactor &D, const double *src, double *dst, int nrhs, bool scatter,
                           hipStream_t st);
 hipError_t launch_extract(const double *vals, const long long *map, double *out, long long count,

@@ -1541,6 +1541,32 @@ k_permute_rows(const double *__restrict__ src, double *__restrict__ dst, const i
     }
 }
 
+// Everything a (re)factorisation needs before its first front kernel, in ONE launch instead of four:
+// the status word, zeros in the big-front buffers (the gather writes only touched entries), the copy of
+// the caller's values, and -- for the fused factor + solve call -- the permuted right-hand sides.
+// One flat index space, cut into the four jobs.
+__global__ void __launch_bounds__(256)
+k_prologue(int *status, double *__restrict__ pool, long long big_begin, long long nzero, long long pool_stride,
+           long long batch, const double *__restrict__ ax_src, double *__restrict__ ax_dst, long long nax,
+           const double *__restrict__ x_src, double *__restrict__ xp, const int *__restrict__ q, long long n, int nrhs)
+{
+    const long long t0 = (long long) blockIdx.x * blockDim.x + threadIdx.x, stride = (long long) gridDim.x * blockDim.x;
+    if (t0 == 0) *status = 0x7f7f7f7f;
+    const long long z_all = nzero * batch, x_all = x_src ? n * nrhs * batch : 0;
+    for (long long t = t0; t < z_all + nax + x_all; t += stride) {
+        if (t < z_all) {
+            pool[(t / nzero) * pool_stride + big_begin + t % nzero] = 0.0;
+        } else if (t < z_all + nax) {
+            const long long e = t - z_all;
+            ax_dst[e] = ax_src[e];
+        } else {
+            const long long e = t - z_all - nax, per = n * nrhs;
+            const long long b = e / per, k = (e % per) / nrhs, c = e % nrhs;
+            xp[e] = x_src[b * per + (long long) q[k] * nrhs + c];
+        }
+    }
+}
+
 // out[p] = map[p] < 0 ? 1.0 : vals[map[p]]
 __global__ void __launch_bounds__(256)
 k_extract(const double *__restrict__ vals, const long long *__restrict__ map,
@@ -1784,12 +1810,7 @@ static hipError_t run_level(const std::vector<LaunchGroup> &groups, size_t g0, s
 hipError_t launch_factor_levels(const DeviceFactor &D, const std::vector<LaunchGroup> &groups,
                                 double inv_tol, hipStream_t st, ForkJoin &fj)
 {
-    fj.rewind();
-    if (D.vals_size > D.big_begin) {     // big-front buffers start from zero: the gather writes only touched entries
-        hipError_t e = hipMemset2DAsync(D.pool + D.big_begin, (size_t) D.pool_size * sizeof(double), 0,
-                                        (size_t) (D.vals_size - D.big_begin) * sizeof(double), (size_t) D.batch, st);
-        if (e != hipSuccess) return e;
-    }
+    fj.rewind();                         // (the big-front buffers were zeroed by launch_prologue)
     for (size_t g0 = 0; g0 < groups.size(); ) {
         size_t g1 = g0;
         while (g1 < groups.size() && groups[g1].level == groups[g0].level) ++g1;
@@ -1971,11 +1992,6 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
     const std::vector<LaunchGroup> sgroups = sweep_groups(all_sgroups, nrhs);
     fj.rewind();
     hipError_t e;
-    if (D.vals_size > D.big_begin) {
-        e = hipMemset2DAsync(D.pool + D.big_begin, (size_t) D.pool_size * sizeof(double), 0,
-                             (size_t) (D.vals_size - D.big_begin) * sizeof(double), (size_t) D.batch, st);
-        if (e != hipSuccess) return e;
-    }
     const int nlevels = fgroups.empty() ? 0 : fgroups.back().level + 1;
     std::vector<long long> tail(nlevels + 1, 0), head(nlevels + 1, 0);   // factor cost of levels >= l; sweep cost of levels < l
     for (const LaunchGroup &g : fgroups) tail[g.level] += factor_group_cost(g);
@@ -2019,6 +2035,17 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
     }
     if (swept && (e = hipStreamWaitEvent(st, swept, 0)) != hipSuccess) return e;
     return sweep(fork_level + 1, nlevels, st);
+}
+
+hipError_t launch_prologue(const DeviceFactor &D, const double *ax_src, const double *x_src, int nrhs, hipStream_t st)
+{
+    const long long nzero = D.vals_size - D.big_begin;
+    const long long nax = (ax_src && ax_src != D.ax) ? D.batch * D.nnz_a : 0;
+    const long long total = nzero * D.batch + nax + (x_src ? D.n * (long long) nrhs * D.batch : 0);
+    hipLaunchKernelGGL(k_prologue, dim3(grid_for(std::max<long long>(total, 1), 256)), dim3(256), 0, st, D.status, D.pool,
+                       D.big_begin, nzero, D.pool_size, D.batch, ax_src, D.ax, nax, x_src, D.xp, D.q, D.n, nrhs);
+    CS3_LAUNCH_CHECK();
+    return hipSuccess;
 }
 
 hipError_t launch_permute(const DeviceFactor &D, const double *src, double *dst, int nrhs, bool scatter,

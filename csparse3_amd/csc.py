@@ -65,6 +65,30 @@ class CscMat:
             return C
         raise Exception("Type not supported")
 
+    def to_csr(self):
+        """CSR arrays (Bp, Bi, Bx) of this matrix, on the device (csc.py:466-478 -> csc_to_csr)."""
+        nnz = int(self.indptr[self.n])
+        Bp = np.zeros(self.m + 1, dtype=np.int32)
+        Bi = np.empty(nnz, dtype=np.int32)
+        Bx = np.empty(nnz, dtype=np.float64)
+        _k.csc_to_csr(self.m, self.n, self.indptr, self.indices, self.data, Bp, Bi, Bx)
+        return Bp, Bi, Bx
+
+    def t(self):
+        """Transpose, on the device (csc.py:502-513 -> csc_transpose)."""
+        C = CscMat()
+        C.m, C.n, C.indptr, C.indices, C.data = _k.csc_transpose(self.m, self.n, self.indptr, self.indices, self.data)
+        C.nzmax = len(C.data)
+        return C
+
+    def islands(self):
+        """Islands of the (structurally symmetric) pattern, each sorted (csc.py:515-521 -> find_islands)."""
+        return _k.find_islands(self.n, self.indptr, self.indices)
+
+    def norm(self):
+        """1-norm (csc_norm, csc_numba.py:723-739)."""
+        return _k.csc_norm(self.n, self.indptr, self.data)
+
     # ---- new: factor / solve
     def _analysis(self, kind, order, q):
         key = (kind, order, None if q is None else bytes(np.asarray(q, dtype=np.int32)))

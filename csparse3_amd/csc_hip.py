@@ -87,6 +87,12 @@ def lib():
         L.cs3_csc_usolve.argtypes = [I64, _i32p, _i32p, _f64p, _f64p, I64]
         L.cs3_csc_matvec.argtypes = [I64, I64, _i32p, _i32p, _f64p, _f64p, _f64p, I64]
         L.cs3_csc_stack_4_by_4.argtypes = [I64, I64, _i32p, _i32p, _f64p] * 4 + [_i32p, _i32p, _f64p]
+        L.cs3_csc_transpose.argtypes = [I64, I64, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p]
+        L.cs3_coo_to_csc.argtypes = [I64, I64, I64, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p]
+        L.cs3_csc_norm.argtypes = [I64, _i32p, _f64p, C.POINTER(C.c_double)]
+        L.cs3_csc_add.argtypes = [I64, I64, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p, C.c_double, C.c_double, _i32p, _i32p, _f64p]
+        L.cs3_csc_sub_matrix.argtypes = [I64, _i32p, _i32p, _f64p, _i32p, I64, _i32p, I64, _i32p, _i32p, _f64p]
+        L.cs3_find_islands.argtypes = [I64, _i32p, _i32p, _i32p]
         _lib = L
     return _lib
 
@@ -365,3 +371,74 @@ def csc_stack_4_by_4_ff(am, an, Ai, Ap, Ax, bm, bn, Bi, Bp, Bx, cm, cn, Ci, Cp, 
                                       cm, cn, _pi(a[6]), _pi(a[7]), _pf(a[8]), dm, dn, _pi(a[9]), _pi(a[10]), _pf(a[11]),
                                       _pi(Pi), _pi(Pp), _pf(Px)))
     return am + cm, an + bn, Pi, Pp, Px
+
+
+# ---- format conversions and utilities on the device ------------------------
+# Names, argument order and return shapes of the reference's own kernels (csc_numba.py); outputs are
+# bit-identical with them, output order included.
+
+def csc_transpose(m, n, Ap, Ai, Ax):
+    """C = A' -> (n, m, Cp, Ci, Cx) as csc_transpose (csc_numba.py:400-436): m and n swapped in the result."""
+    Ap, Ai, Ax = _i32(Ap), _i32(Ai), _f64(Ax)
+    nnz = int(Ap[n])
+    Cp = np.empty(m + 1, dtype=np.int32); Ci = np.empty(nnz, dtype=np.int32); Cx = np.empty(nnz, dtype=np.float64)
+    _check(lib().cs3_csc_transpose(m, n, _pi(Ap), _pi(Ai), _pf(Ax), _pi(Cp), _pi(Ci), _pf(Cx)))
+    return n, m, Cp, Ci, Cx
+
+
+def csc_to_csr(m, n, Ap, Ai, Ax, Bp, Bi, Bx):
+    """CSR arrays of A written into the caller's Bp[m + 1], Bi[nnz], Bx[nnz], as csc_to_csr (csc_numba.py:360-397)."""
+    Ap, Ai, Ax = _i32(Ap), _i32(Ai), _f64(Ax)
+    for a, t in ((Bp, np.int32), (Bi, np.int32), (Bx, np.float64)):
+        assert isinstance(a, np.ndarray) and a.dtype == t and a.flags.c_contiguous
+    _check(lib().cs3_csc_transpose(m, n, _pi(Ap), _pi(Ai), _pf(Ax), _pi(Bp), _pi(Bi), _pf(Bx)))
+
+
+def coo_to_csc(m, n, Ti, Tj, Tx, nz):
+    """Triplets -> (m, n, Cp, Ci, Cx); duplicates kept, triplet order inside a column (csc_numba.py:331-357)."""
+    Ti, Tj, Tx = _i32(Ti), _i32(Tj), _f64(Tx)
+    Cp = np.empty(n + 1, dtype=np.int32); Ci = np.empty(nz, dtype=np.int32); Cx = np.empty(nz, dtype=np.float64)
+    _check(lib().cs3_coo_to_csc(m, n, nz, _pi(Ti), _pi(Tj), _pf(Tx), _pi(Cp), _pi(Ci), _pf(Cx)))
+    return m, n, Cp, Ci, Cx
+
+
+def csc_norm(n, Ap, Ax):
+    """1-norm (csc_numba.py:723-739)."""
+    Ap, Ax = _i32(Ap), _f64(Ax)
+    out = C.c_double(0.0)
+    _check(lib().cs3_csc_norm(n, _pi(Ap), _pf(Ax), C.byref(out)))
+    return float(out.value)
+
+
+def csc_add_ff(Am, An, Ap, Ai, Ax, Bm, Bn, Bp, Bi, Bx, alpha, beta):
+    """C = alpha A + beta B -> (m, n, Cp, Ci, Cx) as csc_add_ff (csc_numba.py:183-219)."""
+    assert Am == Bm and An == Bn
+    Ap, Ai, Ax, Bp, Bi, Bx = _i32(Ap), _i32(Ai), _f64(Ax), _i32(Bp), _i32(Bi), _f64(Bx)
+    cap = int(Ap[An]) + int(Bp[Bn])
+    Cp = np.empty(An + 1, dtype=np.int32); Ci = np.empty(max(cap, 1), dtype=np.int32); Cx = np.empty(max(cap, 1), dtype=np.float64)
+    _check(lib().cs3_csc_add(Am, An, _pi(Ap), _pi(Ai), _pf(Ax), _pi(Bp), _pi(Bi), _pf(Bx), alpha, beta, _pi(Cp), _pi(Ci), _pf(Cx)))
+    nz = int(Cp[An])
+    return Am, An, Cp, Ci[:nz].copy(), Cx[:nz].copy()
+
+
+def csc_sub_matrix(Am, Anz, Ap, Ai, Ax, rows, cols):
+    """A[rows, cols] -> (nnz, Bp, Bi, Bx) exactly as csc_sub_matrix computes it (csc_numba.py:464-502): the new row
+    index is that function's running match counter, not the position of the row in `rows`."""
+    Ap, Ai, Ax, rows, cols = _i32(Ap), _i32(Ai), _f64(Ax), _i32(rows), _i32(cols)
+    n = len(Ap) - 1
+    Bp = np.empty(len(cols) + 1, dtype=np.int32); Bi = np.empty(max(Anz, 1), dtype=np.int32); Bx = np.zeros(max(Anz, 1), dtype=np.float64)
+    _check(lib().cs3_csc_sub_matrix(n, _pi(Ap), _pi(Ai), _pf(Ax), _pi(rows), len(rows), _pi(cols), len(cols), _pi(Bp), _pi(Bi), _pf(Bx)))
+    nz = int(Bp[len(cols)])
+    return nz, Bp, Bi[:nz].copy(), Bx[:nz].copy()
+
+
+def find_islands(node_number, indptr, indices):
+    """Islands of the pattern as find_islands / CscMat.islands give them (csc_numba.py:744-808, csc.py:515-521):
+    a list of islands ordered by their smallest node, each a sorted int32 array."""
+    Ap, Ai = _i32(indptr), _i32(indices)
+    label = np.empty(node_number, dtype=np.int32)
+    _check(lib().cs3_find_islands(node_number, _pi(Ap), _pi(Ai), _pi(label)))
+    order = np.argsort(label, kind="stable")
+    cuts = np.flatnonzero(np.diff(label[order])) + 1
+    return [g.astype(np.int32) for g in np.split(order, cuts)] if node_number else []
+

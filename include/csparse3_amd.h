@@ -178,6 +178,32 @@ int cs3_csc_stack_4_by_4(int64_t am, int64_t an, const int32_t *Ai, const int32_
                          int64_t dm, int64_t dn, const int32_t *Di, const int32_t *Dp, const double *Dx,
                          int32_t *Pi, int32_t *Pp, double *Px);
 
+/* ---- format conversions and utilities on the device ----
+ * Same outputs as the reference's Python kernels, bit for bit (tests/golden/): output ORDER included.
+ * Host pointers in and out; results are caller-allocated. */
+/* C = A' (csc_transpose, csc_numba.py:400-436); the same three arrays are A in CSR form
+ * (csc_to_csr, :360-397).  Cp[m + 1], Ci / Cx[nnz]. */
+int cs3_csc_transpose(int64_t m, int64_t n, const int32_t *Ap, const int32_t *Ai, const double *Ax,
+                      int32_t *Cp, int32_t *Ci, double *Cx);
+/* Triplets to CSC, duplicates kept, triplet order inside a column (coo_to_csc, csc_numba.py:331-357). */
+int cs3_coo_to_csc(int64_t m, int64_t n, int64_t nz, const int32_t *Ti, const int32_t *Tj, const double *Tx,
+                   int32_t *Cp, int32_t *Ci, double *Cx);
+/* 1-norm: max column sum of |x| (csc_norm, csc_numba.py:723-739). */
+int cs3_csc_norm(int64_t n, const int32_t *Ap, const double *Ax, double *norm);
+/* C = alpha A + beta B (csc_add_ff, csc_numba.py:183-219).  Ci / Cx: room for nnz(A) + nnz(B); used: Cp[n]. */
+int cs3_csc_add(int64_t m, int64_t n, const int32_t *Ap, const int32_t *Ai, const double *Ax,
+                const int32_t *Bp, const int32_t *Bi, const double *Bx, double alpha, double beta,
+                int32_t *Cp, int32_t *Ci, double *Cx);
+/* B = A[rows, cols] exactly as csc_sub_matrix computes it (csc_numba.py:464-502), its running row counter
+ * included.  Bp[ncols + 1]; Bi / Bx: room for nnz(A); used: Bp[ncols]. */
+int cs3_csc_sub_matrix(int64_t n, const int32_t *Ap, const int32_t *Ai, const double *Ax,
+                       const int32_t *rows, int64_t nrows, const int32_t *cols, int64_t ncols,
+                       int32_t *Bp, int32_t *Bi, double *Bx);
+/* label[i] = smallest node of the island (connected component of the pattern, either direction) that holds
+ * node i: find_islands (csc_numba.py:744-808) lists islands by ascending smallest node, CscMat.islands
+ * (csc.py:515-521) sorts each -- both follow from the labels. */
+int cs3_find_islands(int64_t n, const int32_t *Ap, const int32_t *Ai, int32_t *label);
+
 #ifdef __cplusplus
 }
 #endif

@@ -220,6 +220,77 @@ orc_csc *orc_coo_to_csc(i64 m, i64 n, const i32 *Ti, const i32 *Tj,
     return C;
 }
 
+/* csc_sub_matrix, csc_numba.py:464-502, statement by statement -- including its
+ * row numbering: `i` is a running counter that advances on every match and is
+ * bumped from 0 to 1 after a selected row without one; it is NOT the position of
+ * the row in `rows`.  Returns a CSC with n = ncols columns (m is not defined by
+ * the reference; the number of selected rows is recorded). */
+orc_csc *orc_sub_matrix(i64 An, const i32 *Ap, const i32 *Ai, const double *Ax,
+                        const i32 *rows, i64 nrows, const i32 *cols, i64 ncols)
+{
+    (void) An;
+    i64 cap = 0;
+    for (i64 c = 0; c < ncols; c++) cap += (i64) (Ap[cols[c] + 1] - Ap[cols[c]]) * (nrows > 0 ? 1 : 0);
+    /* a row listed twice matches twice: size for the worst case */
+    cap = cap * (nrows > 0 ? nrows : 1);
+    if (cap > ((i64) 1 << 28)) cap = (i64) 1 << 28;
+    orc_csc *B = csc_alloc(nrows, ncols, cap > 0 ? cap : 1, 1);
+    if (!B) return NULL;
+    i64 n = 0;
+    B->p[0] = 0;
+    for (i64 c = 0; c < ncols; c++) {
+        i32 j = cols[c];
+        i32 i = 0;
+        for (i64 rr = 0; rr < nrows; rr++) {
+            i32 r = rows[rr];
+            for (i32 k = Ap[j]; k < Ap[j + 1]; k++) {
+                if (Ai[k] == r) {
+                    if (n >= cap) { orc_csc_free(B); return NULL; }
+                    B->x[n] = Ax[k];
+                    B->i[n] = i;
+                    i++;
+                    n++;
+                }
+            }
+            if (i == 0) i++;
+        }
+        B->p[c + 1] = (i32) n;
+    }
+    return B;
+}
+
+/* find_islands, csc_numba.py:744-808: walk from every unvisited node in ascending
+ * order, first-in first-out (the reference pops the front of its "stack"),
+ * following the entries of column v to their row indices.  island_of[v] receives
+ * the index of v's island; returns the number of islands.  The sort of every
+ * island done by CscMat.islands (csc.py:515-521) is left to the caller. */
+int64_t orc_find_islands(i64 n, const i32 *Ap, const i32 *Ai, i32 *island_of)
+{
+    unsigned char *visited = (unsigned char *) xcalloc(n > 0 ? n : 1, 1);
+    i64 cap = (n > 0 ? n : 1) + (Ap ? (i64) Ap[n] : 0) + 1;
+    i32 *queue = (i32 *) xcalloc(cap, sizeof(i32));
+    if (!visited || !queue) { free(visited); free(queue); return -1; }
+    i64 count = 0;
+    for (i64 node = 0; node < n; node++) {
+        if (visited[node]) continue;
+        i64 head = 0, tail = 0;
+        queue[tail++] = (i32) node;
+        while (head < tail) {
+            i32 v = queue[head++];
+            if (visited[v]) continue;
+            visited[v] = 1;
+            island_of[v] = (i32) count;
+            for (i32 p = Ap[v]; p < Ap[v + 1]; p++) {
+                i32 k = Ai[p];
+                if (!visited[k] && tail < cap) queue[tail++] = k;
+            }
+        }
+        count++;
+    }
+    free(visited); free(queue);
+    return count;
+}
+
 /* csc_stack_4_by_4_ff, csc_numba.py:640-720 -- argument order (m, n,
  * indices, indptr, data) as in the reference.  [[A, B], [C, D]]. */
 orc_csc *orc_stack_4_by_4(i64 am, i64 an, const i32 *Ai, const i32 *Ap, const double *Ax,

@@ -58,6 +58,9 @@ void orc_mat_vec(int64_t m, int64_t n, const int32_t *Ap, const int32_t *Ai,
 void orc_mat_vecs(int64_t m, int64_t n, int64_t k, const int32_t *Ap,
                   const int32_t *Ai, const double *Ax, const double *X, double *Y);
 double orc_norm(int64_t n, const int32_t *Ap, const double *Ax);
+orc_csc *orc_sub_matrix(int64_t An, const int32_t *Ap, const int32_t *Ai, const double *Ax,
+                        const int32_t *rows, int64_t nrows, const int32_t *cols, int64_t ncols);
+int64_t orc_find_islands(int64_t n, const int32_t *Ap, const int32_t *Ai, int32_t *island_of);
 orc_csc *orc_coo_to_csc(int64_t m, int64_t n, const int32_t *Ti,
                         const int32_t *Tj, const double *Tx, int64_t nz);
 orc_csc *orc_stack_4_by_4(int64_t am, int64_t an, const int32_t *Ai, const int32_t *Ap, const double *Ax,

@@ -57,6 +57,8 @@ def lib():
         _lib.orc_symperm.restype = _CscP
         _lib.orc_permute.restype = _CscP
         _lib.orc_norm.restype = C.c_double
+        _lib.orc_sub_matrix.restype = _CscP
+        _lib.orc_find_islands.restype = C.c_int64
         _lib.orc_cumsum.restype = C.c_int64
         _lib.orc_scatter.restype = C.c_int64
         _lib.orc_csc_free.argtypes = [_CscP]
@@ -146,6 +148,25 @@ def csc_mat_vecs(m, n, Ap, Ai, Ax, X):
 def csc_norm(n, Ap, Ax):
     Ap, Ax = _i32(Ap), _f64(Ax)
     return float(lib().orc_norm(I64(n), _pi(Ap), _pf(Ax)))
+
+
+def csc_sub_matrix(Am, Anz, Ap, Ai, Ax, rows, cols):
+    """-> (nnz, Bp, Bi, Bx) as csc_sub_matrix (csc_numba.py:464-502)."""
+    Ap, Ai, Ax, rows, cols = _i32(Ap), _i32(Ai), _f64(Ax), _i32(rows), _i32(cols)
+    r = lib().orc_sub_matrix(I64(len(Ap) - 1), _pi(Ap), _pi(Ai), _pf(Ax), _pi(rows), I64(len(rows)), _pi(cols), I64(len(cols)))
+    _, _, Bp, Bi, Bx = _take(r)
+    return int(Bp[len(cols)]), Bp, Bi, Bx
+
+
+def find_islands(node_number, indptr, indices):
+    """Islands as find_islands lists them (csc_numba.py:744-808), each sorted as CscMat.islands does (csc.py:515-521)."""
+    Ap, Ai = _i32(indptr), _i32(indices)
+    of = np.zeros(max(node_number, 1), dtype=np.int32)
+    cnt = int(lib().orc_find_islands(I64(node_number), _pi(Ap), _pi(Ai), _pi(of)))
+    if cnt < 0:
+        raise MemoryError("oracle: find_islands")
+    of = of[:node_number]
+    return [np.flatnonzero(of == c).astype(np.int32) for c in range(cnt)]
 
 
 def coo_to_csc(m, n, Ti, Tj, Tx, nz):

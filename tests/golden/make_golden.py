@@ -146,6 +146,47 @@ def main():
                                                  cm, an, Ci_, Cp_, Cx_, cm, bn, Di_, Dp_, Dx_)
     out.update(st_m=sm, st_n=sn, st_i=Si, st_p=Sp, st_x=Sx)
 
+    # ---- appended later (after every draw above, so the arrays above keep their values) --------------------
+    # sub-matrix extraction, the reference's own semantics (csc_sub_matrix, csc_numba.py:464-502), on case r1
+    Ap, Ai, Ax = out["r1_Ap"], out["r1_Ai"], out["r1_Ax"]
+    for tag, (rows, cols) in {"sub1": (np.array([3, 4, 10, 11, 30, 2], dtype=np.int32), np.array([0, 5, 6, 20, 39, 5], dtype=np.int32)),
+                              "sub2": (np.arange(40, dtype=np.int32), np.array([7, 8, 9], dtype=np.int32)),
+                              "sub3": (np.array([39, 0, 17], dtype=np.int32), np.arange(0, 40, 3, dtype=np.int32))}.items():
+        nz, Sp_, Si_, Sx_ = ref.csc_sub_matrix(40, int(Ap[40]), Ap, Ai, Ax, rows, cols)
+        out.update({tag + "_rows": rows, tag + "_cols": cols, tag + "_nz": np.int64(nz), tag + "_p": Sp_, tag + "_i": Si_, tag + "_x": Sx_})
+    # duplicates and unsorted rows: the order transpose / to_csr / coo_to_csc / add give them
+    dAp = np.array([0, 4, 4, 7, 9], dtype=np.int32)
+    dAi = np.array([2, 0, 2, 1, 3, 3, 0, 1, 1], dtype=np.int32)
+    dAx = np.array([1.0, 2.0, 0.5, -3.0, 4.0, 0.25, 7.0, -1.5, 2.5])
+    out.update(dup_Ap=dAp, dup_Ai=dAi, dup_Ax=dAx)
+    _, _, Tp, Ti, Tx = ref.csc_transpose(4, 4, dAp, dAi, dAx)
+    out.update(dup_t_p=Tp, dup_t_i=Ti[:Tp[4]], dup_t_x=Tx[:Tp[4]])
+    _, _, Cp, Ci, Cx = ref.csc_add_ff(4, 4, dAp, dAi, dAx, 4, 4, dAp, dAi, dAx, 2.0, 0.5)
+    out.update(dup_add_p=Cp, dup_add_i=Ci[:Cp[4]], dup_add_x=Cx[:Cp[4]])
+    dcols = np.repeat(np.arange(4, dtype=np.int32), np.diff(dAp))
+    perm = np.array([4, 0, 8, 2, 6, 1, 7, 3, 5])
+    _, _, Kp, Ki, Kx = ref.coo_to_csc(4, 4, dAi[perm].copy(), dcols[perm].copy(), dAx[perm].copy(), 9)
+    out.update(dup_coo_i=dAi[perm].copy(), dup_coo_j=dcols[perm].copy(), dup_coo_x=dAx[perm].copy(),
+               dup_coo_p=Kp, dup_coo_ci=Ki[:Kp[4]], dup_coo_cx=Kx[:Kp[4]])
+    out["dup_norm"] = np.float64(ref.csc_norm(4, dAp, dAx))
+    # islands: five components scattered over 30 nodes, unsymmetric pattern (find_islands, csc_numba.py:744-808,
+    # followed by the per-island sort of CscMat.islands, csc.py:515-521)
+    rng2 = np.random.default_rng(77)
+    comp = rng2.integers(0, 5, size=30)
+    ei, ej = [], []
+    for c in range(5):
+        nodes = np.flatnonzero(comp == c)
+        for a, b in zip(nodes[:-1], nodes[1:]):            # a path through the component, one direction only
+            ei.append(b); ej.append(a)
+        if len(nodes) > 2:
+            ei.append(nodes[0]); ej.append(nodes[-1])
+    ei = np.array(ei + list(range(30)), dtype=np.int32); ej = np.array(ej + list(range(30)), dtype=np.int32)
+    _, _, Ip, Ii, _ = ref.coo_to_csc(30, 30, ei, ej, np.ones(len(ei)), len(ei))
+    isl = ref.find_islands(30, Ip, Ii[:Ip[30]])
+    isl = [np.sort(np.array(list(x), dtype=np.int32)) for x in isl]
+    out.update(isl_Ap=Ip, isl_Ai=Ii[:Ip[30]], isl_count=np.int64(len(isl)),
+               isl_flat=np.concatenate(isl).astype(np.int32), isl_sizes=np.array([len(x) for x in isl], dtype=np.int32))
+
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, "with", len(out), "arrays")
 

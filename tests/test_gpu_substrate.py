@@ -1,0 +1,134 @@
+"""Device versions of the reference's substrate kernels, through the C ABI.
+Bit-exact against (a) the golden vectors = outputs of the reference's own Python kernels
+(tests/golden/make_golden.py) and (b) the CPU oracle on larger seeded inputs."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import csc_to_scipy
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "substrate.npz"))
+
+
+def _same(a, b):
+    return all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("tag", ["doc", "r1", "r2", "r3"])
+def test_transpose_to_csr_norm_match_golden(gpu, tag):
+    m, n = int(GOLD[tag + "_m"]), int(GOLD[tag + "_n"])
+    Ap, Ai, Ax = GOLD[tag + "_Ap"], GOLD[tag + "_Ai"], GOLD[tag + "_Ax"]
+    tn, tm, Tp, Ti, Tx = gpu.csc_transpose(m, n, Ap, Ai, Ax)
+    assert (tn, tm) == (n, m)                                   # the reference returns the swapped shape
+    assert _same((Tp, Ti, Tx), (GOLD[tag + "_t_p"], GOLD[tag + "_t_i"], GOLD[tag + "_t_x"]))
+    Bp = np.zeros(m + 1, dtype=np.int32); Bi = np.empty(int(Ap[n]), dtype=np.int32); Bx = np.empty(int(Ap[n]))
+    gpu.csc_to_csr(m, n, Ap, Ai, Ax, Bp, Bi, Bx)
+    assert _same((Bp, Bi, Bx), (GOLD[tag + "_csr_p"], GOLD[tag + "_csr_i"], GOLD[tag + "_csr_x"]))
+    assert gpu.csc_norm(n, Ap, Ax) == float(GOLD[tag + "_norm"])
+
+
+@pytest.mark.parametrize("tag", ["r1", "r2", "r3"])
+def test_add_and_coo_match_golden(gpu, tag):
+    m, n = int(GOLD[tag + "_m"]), int(GOLD[tag + "_n"])
+    Ap, Ai, Ax = GOLD[tag + "_Ap"], GOLD[tag + "_Ai"], GOLD[tag + "_Ax"]
+    _, _, Cp, Ci, Cx = gpu.csc_add_ff(m, n, Ap, Ai, Ax, m, n, GOLD[tag + "_Bp"], GOLD[tag + "_Bi"], GOLD[tag + "_Bx"], 1.5, -0.25)
+    assert _same((Cp, Ci, Cx), (GOLD[tag + "_add_p"], GOLD[tag + "_add_i"], GOLD[tag + "_add_x"]))
+    ti = GOLD[tag + "_coo_i"]
+    _, _, Kp, Ki, Kx = gpu.coo_to_csc(m, n, ti, GOLD[tag + "_coo_j"], GOLD[tag + "_coo_x"], len(ti))
+    assert _same((Kp, Ki, Kx), (GOLD[tag + "_coo_p"], GOLD[tag + "_coo_ci"], GOLD[tag + "_coo_cx"]))
+
+
+def test_duplicates_and_unsorted_rows_keep_the_reference_order(gpu):
+    Ap, Ai, Ax = GOLD["dup_Ap"], GOLD["dup_Ai"], GOLD["dup_Ax"]
+    _, _, Tp, Ti, Tx = gpu.csc_transpose(4, 4, Ap, Ai, Ax)
+    assert _same((Tp, Ti, Tx), (GOLD["dup_t_p"], GOLD["dup_t_i"], GOLD["dup_t_x"]))
+    _, _, Cp, Ci, Cx = gpu.csc_add_ff(4, 4, Ap, Ai, Ax, 4, 4, Ap, Ai, Ax, 2.0, 0.5)
+    assert _same((Cp, Ci, Cx), (GOLD["dup_add_p"], GOLD["dup_add_i"], GOLD["dup_add_x"]))
+    _, _, Kp, Ki, Kx = gpu.coo_to_csc(4, 4, GOLD["dup_coo_i"], GOLD["dup_coo_j"], GOLD["dup_coo_x"], 9)
+    assert _same((Kp, Ki, Kx), (GOLD["dup_coo_p"], GOLD["dup_coo_ci"], GOLD["dup_coo_cx"]))
+    assert gpu.csc_norm(4, Ap, Ax) == float(GOLD["dup_norm"])
+
+
+@pytest.mark.parametrize("tag", ["sub1", "sub2", "sub3"])
+def test_sub_matrix_matches_golden(gpu, tag):
+    Ap, Ai, Ax = GOLD["r1_Ap"], GOLD["r1_Ai"], GOLD["r1_Ax"]
+    nz, Bp, Bi, Bx = gpu.csc_sub_matrix(40, int(Ap[40]), Ap, Ai, Ax, GOLD[tag + "_rows"], GOLD[tag + "_cols"])
+    assert nz == int(GOLD[tag + "_nz"])
+    assert _same((Bp, Bi, Bx), (GOLD[tag + "_p"], GOLD[tag + "_i"], GOLD[tag + "_x"]))
+
+
+def test_find_islands_matches_golden(gpu):
+    isl = gpu.find_islands(30, GOLD["isl_Ap"], GOLD["isl_Ai"])
+    assert len(isl) == int(GOLD["isl_count"]) and [len(x) for x in isl] == list(GOLD["isl_sizes"])
+    assert np.array_equal(np.concatenate(isl), GOLD["isl_flat"])
+
+
+def _random_csc(rng, m, n, per_col, dup=False):
+    cols = np.repeat(np.arange(n), per_col)
+    rows = rng.integers(0, m, size=len(cols))
+    if not dup:
+        key = np.unique(cols.astype(np.int64) * m + rows)
+        cols, rows = (key // m), (key % m)
+        order = rng.permutation(len(key))                       # rows of a column in arbitrary order
+        order = order[np.argsort(cols[order], kind="stable")]
+        cols, rows = cols[order], rows[order]
+    Ap = np.zeros(n + 1, dtype=np.int32); np.add.at(Ap, cols + 1, 1); Ap = np.cumsum(Ap).astype(np.int32)
+    return Ap, rows.astype(np.int32), rng.standard_normal(len(rows))
+
+
+@pytest.mark.parametrize("dup", [False, True])
+def test_conversions_match_oracle_at_size(gpu, orc, dup):
+    rng = np.random.default_rng(31 + dup)
+    m, n = 30011, 20000
+    Ap, Ai, Ax = _random_csc(rng, m, n, 9, dup)
+    Bp, Bi, Bx = _random_csc(rng, m, n, 5, dup)
+    assert _same(gpu.csc_transpose(m, n, Ap, Ai, Ax)[2:], orc.csc_transpose(m, n, Ap, Ai, Ax)[2:])
+    assert gpu.csc_norm(n, Ap, Ax) == orc.csc_norm(n, Ap, Ax)
+    assert _same(gpu.csc_add_ff(m, n, Ap, Ai, Ax, m, n, Bp, Bi, Bx, 0.75, -2.0)[2:],
+                 orc.csc_add_ff(m, n, Ap, Ai, Ax, m, n, Bp, Bi, Bx, 0.75, -2.0)[2:])
+    cols = np.repeat(np.arange(n, dtype=np.int32), np.diff(Ap))
+    perm = rng.permutation(len(Ai))
+    assert _same(gpu.coo_to_csc(m, n, Ai[perm], cols[perm], Ax[perm], len(perm))[2:],
+                 orc.coo_to_csc(m, n, Ai[perm], cols[perm], Ax[perm], len(perm))[2:])
+    # transposing twice sorts the rows of every column and gives the matrix back
+    A = csc_to_scipy(m, n, Ap, Ai, Ax)
+    _, _, Tp, Ti, Tx = gpu.csc_transpose(m, n, Ap, Ai, Ax)
+    _, _, Up, Ui, Ux = gpu.csc_transpose(n, m, Tp, Ti, Tx)
+    assert abs(csc_to_scipy(m, n, Up, Ui, Ux) - A).max() == 0.0
+    assert all(np.all(np.diff(Ui[Up[j]:Up[j + 1]]) >= 0) for j in range(0, n, 997))
+
+
+def test_sub_matrix_and_islands_match_oracle_at_size(gpu, orc):
+    from csparse3_amd import synth
+    rng = np.random.default_rng(5)
+    m, n, Ap, Ai, Ax = synth.grid_jacobian(n=6000, seed=6)
+    rows = rng.choice(n, size=300, replace=False).astype(np.int32)
+    cols = rng.choice(n, size=400, replace=False).astype(np.int32)
+    got = gpu.csc_sub_matrix(m, int(Ap[n]), Ap, Ai, Ax, rows, cols)
+    want = orc.csc_sub_matrix(m, int(Ap[n]), Ap, Ai, Ax, rows, cols)
+    assert got[0] == want[0] and _same(got[1:], want[1:])
+    # a network that falls apart into islands: cut the grid at a few places (pattern stays symmetric)
+    import scipy.sparse as sp
+    A = sp.csc_matrix((Ax, Ai, Ap), shape=(n, n)).tolil()
+    comp = np.minimum(np.arange(n) // 700, 7) + 8 * (rng.random(n) < 0.001)      # 8 slabs + a few isolated nodes
+    A = A.tocoo()
+    keep = comp[A.row] == comp[A.col]
+    P = sp.csc_matrix((A.data[keep], (A.row[keep], A.col[keep])), shape=(n, n)); P.sort_indices()
+    got = gpu.find_islands(n, P.indptr.astype(np.int32), P.indices.astype(np.int32))
+    want = orc.find_islands(n, P.indptr.astype(np.int32), P.indices.astype(np.int32))
+    assert len(got) == len(want) >= 8 and all(np.array_equal(a, b) for a, b in zip(got, want))
+
+
+def test_substrate_rejects_bad_indices(gpu):
+    Ap = np.array([0, 1, 2], dtype=np.int32); Ai = np.array([0, 5], dtype=np.int32); Ax = np.ones(2)
+    with pytest.raises(gpu.Cs3Error):
+        gpu.csc_transpose(2, 2, Ap, Ai, Ax)
+    with pytest.raises(gpu.Cs3Error):
+        gpu.coo_to_csc(2, 2, np.array([0], dtype=np.int32), np.array([9], dtype=np.int32), np.ones(1), 1)
+    # empty inputs
+    z = np.zeros(4, dtype=np.int32)
+    _, _, Tp, Ti, Tx = gpu.csc_transpose(3, 3, z, np.zeros(0, dtype=np.int32), np.zeros(0))
+    assert np.array_equal(Tp, z) and len(Ti) == 0 and gpu.csc_norm(3, z, np.zeros(0)) == 0.0
+    assert [list(x) for x in gpu.find_islands(3, z, np.zeros(0, dtype=np.int32))] == [[0], [1], [2]]

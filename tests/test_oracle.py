@@ -219,3 +219,30 @@ def test_triangular_solves_against_dense(orc):
     assert np.allclose(Ld.T @ x, b)
     x = b.copy(); orc.csc_utsolve_f(n, U.indptr, U.indices, U.data, x)
     assert np.allclose(Ld @ x, b)
+
+
+# ---- section 8f neighbours: sub-matrix extraction, duplicates, islands (golden = the reference's own outputs) ----
+
+@pytest.mark.parametrize("tag", ["sub1", "sub2", "sub3"])
+def test_sub_matrix_matches_reference(orc, tag):
+    Ap, Ai, Ax = GOLD["r1_Ap"], GOLD["r1_Ai"], GOLD["r1_Ax"]
+    nz, Bp, Bi, Bx = orc.csc_sub_matrix(40, int(Ap[40]), Ap, Ai, Ax, GOLD[tag + "_rows"], GOLD[tag + "_cols"])
+    assert nz == int(GOLD[tag + "_nz"])
+    assert np.array_equal(Bp, GOLD[tag + "_p"]) and np.array_equal(Bi, GOLD[tag + "_i"]) and np.array_equal(Bx, GOLD[tag + "_x"])
+
+
+def test_duplicates_and_unsorted_rows_keep_the_reference_order(orc):
+    Ap, Ai, Ax = GOLD["dup_Ap"], GOLD["dup_Ai"], GOLD["dup_Ax"]
+    _, _, Tp, Ti, Tx = orc.csc_transpose(4, 4, Ap, Ai, Ax)
+    assert np.array_equal(Tp, GOLD["dup_t_p"]) and np.array_equal(Ti, GOLD["dup_t_i"]) and np.array_equal(Tx, GOLD["dup_t_x"])
+    _, _, Cp, Ci, Cx = orc.csc_add_ff(4, 4, Ap, Ai, Ax, 4, 4, Ap, Ai, Ax, 2.0, 0.5)
+    assert np.array_equal(Cp, GOLD["dup_add_p"]) and np.array_equal(Ci, GOLD["dup_add_i"]) and np.array_equal(Cx, GOLD["dup_add_x"])
+    _, _, Kp, Ki, Kx = orc.coo_to_csc(4, 4, GOLD["dup_coo_i"], GOLD["dup_coo_j"], GOLD["dup_coo_x"], 9)
+    assert np.array_equal(Kp, GOLD["dup_coo_p"]) and np.array_equal(Ki, GOLD["dup_coo_ci"]) and np.array_equal(Kx, GOLD["dup_coo_cx"])
+    assert orc.csc_norm(4, Ap, Ax) == float(GOLD["dup_norm"])
+
+
+def test_find_islands_matches_reference(orc):
+    isl = orc.find_islands(30, GOLD["isl_Ap"], GOLD["isl_Ai"])
+    assert len(isl) == int(GOLD["isl_count"]) and [len(x) for x in isl] == list(GOLD["isl_sizes"])
+    assert np.array_equal(np.concatenate(isl), GOLD["isl_flat"])

@@ -391,7 +391,7 @@ def test_fresh_handles_reproduce_bitwise_on_big_fronts(gpu):
 
 
 @pytest.mark.parametrize("case", ["grid20k_lu", "denseblock_lu", "spd_chol"])
-@pytest.mark.parametrize("nrhs", [1, 5])
+@pytest.mark.parametrize("nrhs", [1, 5, 40])
 def test_factor_solve_fused_equals_factor_then_solve(gpu, case, nrhs):
     """cs3_factor_solve_dev (forward sweep overlapped with the factorisation) == factor_dev + solve_dev, bit for bit."""
     import torch

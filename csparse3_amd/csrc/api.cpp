@@ -151,6 +151,7 @@ int ensure_rhs_capacity(cs3_handle h, long long nrhs)
     if (D.xp) (void) hipFree(D.xp);
     if (D.bigv) (void) hipFree(D.bigv);
     D.cv = D.xp = D.bigv = nullptr;
+    D.nrhs_cap = 0;                           // nothing usable until all three are back
     CS3_HIP(hipMalloc((void **) &D.cv, std::max<size_t>(1, (size_t) (D.batch * D.cv_size * nrhs)) * sizeof(double)));
     CS3_HIP(hipMalloc((void **) &D.xp, std::max<size_t>(1, (size_t) (D.batch * D.n * nrhs)) * sizeof(double)));
     CS3_HIP(hipMalloc((void **) &D.bigv, std::max<size_t>(1, (size_t) (D.batch * D.bv_size * nrhs)) * sizeof(double)));

@@ -1305,6 +1305,24 @@ struct BlockTriangle {
         }
         rdg = (!FORWARD || KIND == CS3_CHOLESKY) ? recip_diag(L, i, r, lane < bw) : 1.0;
     }
+    // the same for KT right-hand sides at once: one pass over the triangle, KT broadcasts per step
+    template <int KT>
+    __device__ __forceinline__ void solve_multi(double (&vi)[KT], int bw) const
+    {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int jj = 0; jj < SOLVE_BW; ++jj) {
+            const int j = FORWARD ? jj : SOLVE_BW - 1 - jj;
+            if (j < bw) {
+#pragma unroll
+                for (int q = 0; q < KT; ++q) {
+                    if ((!FORWARD || KIND == CS3_CHOLESKY) && lane == j) vi[q] *= rdg;
+                    const double xk = bcast_lane(vi[q], j);
+                    if (FORWARD ? lane > j : lane < j) vi[q] -= t[j] * xk;
+                }
+            }
+        }
+    }
     __device__ __forceinline__ double solve(double vi, int bw) const
     {
         const int lane = threadIdx.x & 63;
@@ -1409,6 +1427,131 @@ k_fwd_big_step(const SolveDesc *__restrict__ sd, int first, int kb,
         if (ke >= w && row >= w && d.parent >= 0)           // last chunk: rows below the pivots are final
             cv_all[(long long) b * cv_stride + (d.cv + row - w) * nrhs + rhs] = nv;
     }
+}
+
+// Many right-hand sides: the same chunk step (64 columns) for BIG_KT right-hand sides per workgroup.  With
+// one right-hand side per workgroup every one of them re-reads the chunk's triangle and its slice of the
+// panel from L2 (64 KB each, 64 MB per launch at 128 right-hand sides: that traffic, not latency, set the
+// launch time); here the operands are read once and applied to BIG_KT vectors.
+constexpr int BIG_KT = 8;
+
+template <int KIND>
+__global__ void __launch_bounds__(256)
+k_fwd_big_step_multi(const SolveDesc *__restrict__ sd, int first, int kb,
+                     const double *__restrict__ pool_all, double *__restrict__ cv_all, double *__restrict__ X_all,
+                     double *__restrict__ bigv_all, int nrhs, long long pool_stride, long long cv_stride,
+                     long long x_stride, long long bv_size)
+{
+    __shared__ double y[BIG_KT][SOLVE_BW];
+    __shared__ double part[4][BIG_KT][64];
+    const SolveDesc d = sd[first + blockIdx.z];
+    const int r = d.r, w = d.w;
+    if (kb >= w) return;
+    const int bw = min(SOLVE_BW, w - kb), ke = kb + bw;
+    const int nsl = (r - ke + 63) / 64;
+    if ((int) blockIdx.x > 0 && (int) blockIdx.x >= nsl) return;
+    const int ntile = (nrhs + BIG_KT - 1) / BIG_KT;
+    const int b = blockIdx.y / ntile, rhs0 = (blockIdx.y % ntile) * BIG_KT, nlive = min(BIG_KT, nrhs - rhs0);
+    const double *L = pool_all + (long long) b * pool_stride + d.lpan;
+    double *v0 = bigv_all + ((long long) b * nrhs + rhs0) * bv_size + d.bv;       // vector q at v0 + q * bv_size
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int row = ke + blockIdx.x * 64 + lane;
+    double ls[16];                                                             // my slice: columns [16 wv, 16 wv + 16)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int jj = wv * 16 + j;
+        ls[j] = load_if(L, (long long) row + (long long) (kb + jj) * r, row < r && jj < bw);
+    }
+    if (wv == 0) {
+        BlockTriangle<KIND, true> ta;
+        ta.load(L, r, kb, bw);
+        double vi[BIG_KT];
+#pragma unroll
+        for (int q = 0; q < BIG_KT; ++q) vi[q] = load_if(v0 + (long long) q * bv_size, kb + lane, lane < bw && q < nlive);
+        ta.template solve_multi<BIG_KT>(vi, bw);
+#pragma unroll
+        for (int q = 0; q < BIG_KT; ++q) y[q][lane] = (lane < bw) ? vi[q] : 0.0;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && tid < bw)
+        for (int q = 0; q < nlive; ++q)
+            X_all[(long long) b * x_stride + (long long) (d.c0 + kb + tid) * nrhs + rhs0 + q] = y[q][tid];
+#pragma unroll
+    for (int q = 0; q < BIG_KT; ++q) {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc += ls[j] * y[q][wv * 16 + j];              // ls[j] = 0 past the chunk
+        part[wv][q][lane] = acc;
+    }
+    __syncthreads();
+    if (tid < 64 && row < r) {
+        for (int q = 0; q < nlive; ++q) {
+            double *vq = v0 + (long long) q * bv_size;
+            const double nv = vq[row] - (((part[0][q][tid] + part[1][q][tid]) + part[2][q][tid]) + part[3][q][tid]);
+            vq[row] = nv;
+            if (ke >= w && row >= w && d.parent >= 0)
+                cv_all[(long long) b * cv_stride + (d.cv + row - w) * nrhs + rhs0 + q] = nv;
+        }
+    }
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256)
+k_bwd_big_step_multi(const SolveDesc *__restrict__ sd, int first, int chunk_from_right,
+                     const double *__restrict__ pool_all, double *__restrict__ X_all, double *__restrict__ bigv_all,
+                     int nrhs, long long pool_stride, long long x_stride, long long bv_size)
+{
+    __shared__ double y[BIG_KT][SOLVE_BW];
+    __shared__ double part[4][BIG_KT][64];
+    const SolveDesc d = sd[first + blockIdx.z];
+    const int r = d.r, w = d.w;
+    const int nchunk = (w + SOLVE_BW - 1) / SOLVE_BW;
+    const int c = nchunk - 1 - chunk_from_right;
+    if (c < 0) return;
+    const int kb = c * SOLVE_BW, bw = min(SOLVE_BW, w - kb);
+    const int nsl = (kb + 63) / 64;
+    if ((int) blockIdx.x > 0 && (int) blockIdx.x >= nsl) return;
+    const int ntile = (nrhs + BIG_KT - 1) / BIG_KT;
+    const int b = blockIdx.y / ntile, rhs0 = (blockIdx.y % ntile) * BIG_KT, nlive = min(BIG_KT, nrhs - rhs0);
+    const double *L = pool_all + (long long) b * pool_stride + d.lpan;
+    double *v0 = bigv_all + ((long long) b * nrhs + rhs0) * bv_size + d.bv;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int row = blockIdx.x * 64 + lane;
+    double us[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int jj = wv * 16 + j;
+        const long long off = (KIND == CS3_LU) ? (long long) row + (long long) (kb + jj) * r
+                                               : (long long) (kb + jj) + (long long) row * r;
+        us[j] = load_if(L, off, row < kb && jj < bw);
+    }
+    if (wv == 0) {
+        BlockTriangle<KIND, false> ta;
+        ta.load(L, r, kb, bw);
+        double vi[BIG_KT];
+#pragma unroll
+        for (int q = 0; q < BIG_KT; ++q) vi[q] = load_if(v0 + (long long) q * bv_size, kb + lane, lane < bw && q < nlive);
+        ta.template solve_multi<BIG_KT>(vi, bw);
+#pragma unroll
+        for (int q = 0; q < BIG_KT; ++q) y[q][lane] = (lane < bw) ? vi[q] : 0.0;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && tid < bw)
+        for (int q = 0; q < nlive; ++q)
+            X_all[(long long) b * x_stride + (long long) (d.c0 + kb + tid) * nrhs + rhs0 + q] = y[q][tid];
+#pragma unroll
+    for (int q = 0; q < BIG_KT; ++q) {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc += us[j] * y[q][wv * 16 + j];
+        part[wv][q][lane] = acc;
+    }
+    __syncthreads();
+    if (tid < 64 && row < kb)
+        for (int q = 0; q < nlive; ++q) {
+            double *vq = v0 + (long long) q * bv_size;
+            vq[row] -= ((part[0][q][tid] + part[1][q][tid]) + part[2][q][tid]) + part[3][q][tid];
+        }
 }
 
 // v = [X rows of my pivots ; X rows of my ancestors], pivot rows minus U12 times the ancestors.
@@ -1871,6 +2014,8 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
     } else if (g.cls == SK_BIG) {
         const unsigned by = (unsigned) (D.batch * nrhs);
         const bool wide = (long long) D.batch * nrhs < 8;      // few right-hand sides: latency-bound, two blocks per launch
+        const bool multi = nrhs >= BIG_KT;                      // many right-hand sides: BIG_KT of them per workgroup
+        const unsigned by_multi = (unsigned) (D.batch * ((nrhs + BIG_KT - 1) / BIG_KT));
         const int cw = wide ? BIG_CW : SOLVE_BW;
         const int nchunk = (g.max_w + cw - 1) / cw;
         const int slices = std::max(1, (g.max_r + 63) / 64);
@@ -1885,6 +2030,9 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
                 if (wide)
                     hipLaunchKernelGGL((k_fwd_big_step<KIND, BIG_CW>), dim3(slices, by, g.count), dim3(256), 0, st, D.sdesc,
                                        g.first, c * cw, D.pool, D.cv, X, D.bigv, nrhs, D.pool_size, cvs, xs, D.bv_size);
+                else if (multi)
+                    hipLaunchKernelGGL((k_fwd_big_step_multi<KIND>), dim3(slices, by_multi, g.count), dim3(256), 0, st, D.sdesc,
+                                       g.first, c * cw, D.pool, D.cv, X, D.bigv, nrhs, D.pool_size, cvs, xs, D.bv_size);
                 else
                     hipLaunchKernelGGL((k_fwd_big_step<KIND, SOLVE_BW>), dim3(slices, by, g.count), dim3(256), 0, st, D.sdesc,
                                        g.first, c * cw, D.pool, D.cv, X, D.bigv, nrhs, D.pool_size, cvs, xs, D.bv_size);
@@ -1898,6 +2046,9 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
             for (int c = 0; c < nchunk; ++c) {
                 if (wide)
                     hipLaunchKernelGGL((k_bwd_big_step<KIND, BIG_CW>), dim3(slices, by, g.count), dim3(256), 0, st, D.sdesc,
+                                       g.first, c, D.pool, X, D.bigv, nrhs, D.pool_size, xs, D.bv_size);
+                else if (multi)
+                    hipLaunchKernelGGL((k_bwd_big_step_multi<KIND>), dim3(slices, by_multi, g.count), dim3(256), 0, st, D.sdesc,
                                        g.first, c, D.pool, X, D.bigv, nrhs, D.pool_size, xs, D.bv_size);
                 else
                     hipLaunchKernelGGL((k_bwd_big_step<KIND, SOLVE_BW>), dim3(slices, by, g.count), dim3(256), 0, st, D.sdesc,

@@ -556,8 +556,10 @@ __device__ __forceinline__ void eliminate32(double (&d)[BIG_NB], bool keep_unsca
 //     underneath (eliminate32: waves 0 and 1 take 32 tile rows each), which yields
 //     L[I, kb:ke] = C U_D^-1   or   U[kb:ke, J] = L_D^-1 C   directly.
 // The factored D cannot be written into F during the launch (the other tiles read the
-// unfactored block), so tile (0,0) parks it in dbuf; the closing launch (kb >= w:
-// last update only) copies the parked blocks into place.
+// unfactored block), so tile (0,0) parks it in dbuf and copies it into place at the NEXT launch
+// (the closing launch, kb >= w: last update only, for the last block): after launch b + 1 every
+// column of the factor up to block b is final in F, which is what lets the forward sweep of a
+// chunk start while later blocks are still being factorised.
 // Tile index 0 = the panel block [kb, ke); index t >= 1 = 64 rows/columns from ke + 64 (t-1).
 template <int KIND>
 __global__ void __launch_bounds__(256)
@@ -591,18 +593,15 @@ k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__res
     const int nsl = (r - ke + 63) / 64;
     if (bi > nsl || bj > nsl) return;
     if (KIND == CS3_CHOLESKY && bi < bj) return;
-    if (!has_panel) {
-        if (bi == 0 && bj == 0) {                   // closing launch: parked diagonal blocks go home
-            for (int blk = 0; blk < nblk; ++blk) {
-                const int k0 = blk * BIG_NB, cw = min(BIG_NB, w - k0);
-                for (int e = tid; e < cw * cw; e += 256) {
-                    const int i = e % cw, j = e / cw;
-                    if (KIND == CS3_LU || i >= j) F[(k0 + i) + (k0 + j) * ld] = dbuf[blk * (BIG_NB * BIG_NB) + i + j * BIG_NB];
-                }
-            }
+    if (kb > 0 && bi == 0 && bj == 0) {             // the diagonal block parked by the previous launch goes home:
+        const int blk = kb / BIG_NB - 1;            // nobody reads that part of F any more (for the last block
+        const int k0 = blk * BIG_NB, cw = min(BIG_NB, w - k0);      // this is the closing launch)
+        for (int e = tid; e < cw * cw; e += 256) {
+            const int i = e % cw, j = e / cw;
+            if (KIND == CS3_LU || i >= j) F[(k0 + i) + (k0 + j) * ld] = dbuf[blk * (BIG_NB * BIG_NB) + i + j * BIG_NB];
         }
-        if (bi == 0 || bj == 0) return;
     }
+    if (!has_panel && (bi == 0 || bj == 0)) return;
     const int row0 = (bi == 0) ? kb : ke + (bi - 1) * 64, nrow = (bi == 0) ? bw : min(64, r - row0);
     const int col0 = (bj == 0) ? kb : ke + (bj - 1) * 64, ncol = (bj == 0) ? bw : min(64, r - col0);
     const bool needs_d = has_panel && (bi == 0 || bj == 0);
@@ -1823,30 +1822,44 @@ static int grid_for(long long work, int block, int cap = 4096)
     return (int) g;
 }
 
+// A group of big fronts = one gather launch, then launches 0 .. nblk of the block step (nblk = closing).
+static int big_group_blocks(const LaunchGroup &g) { return (g.max_w + BIG_NB - 1) / BIG_NB; }
+
+static hipError_t launch_big_gather(const DeviceFactor &D, const LaunchGroup &g, hipStream_t st)
+{
+    const int chunks = (int) (g.max_asm >> 6);
+    const int gx = std::max(1, std::min(64, (chunks + 4 * GATHER_UNROLL - 1) / (4 * GATHER_UNROLL)));
+    hipLaunchKernelGGL(k_big_gather, dim3(gx, (unsigned) D.batch, g.count), dim3(256), 0, st, D.fdesc, g.first,
+                       D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool, D.nnz_a, D.pool_size);
+    CS3_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+template <int KIND>
+static hipError_t launch_big_block(const DeviceFactor &D, const LaunchGroup &g, int blk, double inv_tol, hipStream_t st)
+{
+    const unsigned batch = (unsigned) D.batch;
+    const int kb = blk * BIG_NB;
+    // trailing region starts at ke >= kb + 1 for a front with a panel here, and at
+    // w >= kb - BIG_NB + 1 for a front whose closing launch this is
+    const int start = std::max(1, kb - BIG_NB + 1);
+    const int rem = g.max_r - std::min(start, g.max_r);        // largest trailing order over the group
+    const int tiles = 1 + (rem + 63) / 64;
+    hipLaunchKernelGGL((k_big_step<KIND>), dim3(tiles, tiles, g.count * batch), dim3(256), 0, st, D.fdesc,
+                       g.first, kb, D.pool, D.pool_size, D.dbuf, D.dbuf_size, inv_tol, D.status, (int) batch, D.tbuf);
+    CS3_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
 template <int KIND>
 static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g, double inv_tol, hipStream_t st)
 {
     const unsigned batch = (unsigned) D.batch;
     if (g.cls == FC_BIG) {
-        const int chunks = (int) (g.max_asm >> 6);
-        const int gx = std::max(1, std::min(64, (chunks + 4 * GATHER_UNROLL - 1) / (4 * GATHER_UNROLL)));
-        hipLaunchKernelGGL(k_big_gather, dim3(gx, batch, g.count), dim3(256), 0, st, D.fdesc, g.first,
-                           D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool, D.nnz_a, D.pool_size);
-        CS3_LAUNCH_CHECK();
-        // one launch per block of BIG_NB pivots, plus the closing launch (last update + parked blocks)
-        const int nblk = (g.max_w + BIG_NB - 1) / BIG_NB;
-        for (int blk = 0; blk <= nblk; ++blk) {
-            const int kb = blk * BIG_NB;
-            // trailing region starts at ke >= kb + 1 for a front with a panel here, and at
-            // w >= kb - BIG_NB + 1 for a front whose closing launch this is
-            const int start = std::max(1, kb - BIG_NB + 1);
-            const int rem = g.max_r - std::min(start, g.max_r);        // largest trailing order over the group
-            const int tiles = 1 + (rem + 63) / 64;
-            hipLaunchKernelGGL((k_big_step<KIND>), dim3(tiles, tiles, g.count * batch), dim3(256), 0, st, D.fdesc,
-                               g.first, kb, D.pool, D.pool_size, D.dbuf, D.dbuf_size, inv_tol, D.status, (int) batch, D.tbuf);
-            CS3_LAUNCH_CHECK();
-        }
-        return hipSuccess;
+        hipError_t e = launch_big_gather(D, g, st);
+        // one launch per block of BIG_NB pivots, plus the closing launch (last update + last parked block)
+        for (int blk = 0; e == hipSuccess && blk <= big_group_blocks(g); ++blk) e = launch_big_block<KIND>(D, g, blk, inv_tol, st);
+        return e;
     }
     dim3 grid((unsigned) g.count, batch);
     const size_t ld = (size_t) (g.max_r | 1);
@@ -1967,6 +1980,85 @@ hipError_t launch_factor_levels(const DeviceFactor &D, const std::vector<LaunchG
     return hipSuccess;
 }
 
+// Sweeps over a group of wide big fronts: a preparation launch, then one launch per chunk of columns.
+struct BigSweepPlan {
+    bool wide, multi;       // two 64-blocks per launch (latency-bound); BIG_KT right-hand sides per workgroup
+    int cw, nchunk, slices;
+    unsigned by, by_multi;
+};
+
+static BigSweepPlan big_sweep_plan(const DeviceFactor &D, const LaunchGroup &g, int nrhs)
+{
+    BigSweepPlan pl;
+    pl.by = (unsigned) (D.batch * nrhs);
+    pl.wide = (long long) D.batch * nrhs < 8;
+    pl.multi = nrhs >= BIG_KT;
+    pl.by_multi = (unsigned) (D.batch * ((nrhs + BIG_KT - 1) / BIG_KT));
+    pl.cw = pl.wide ? BIG_CW : SOLVE_BW;
+    pl.nchunk = (g.max_w + pl.cw - 1) / pl.cw;
+    pl.slices = std::max(1, (g.max_r + 63) / 64);
+    return pl;
+}
+
+static hipError_t launch_fwd_big_pre(const DeviceFactor &D, const LaunchGroup &g, double *X, int nrhs, hipStream_t st)
+{
+    const BigSweepPlan pl = big_sweep_plan(D, g, nrhs);
+    // rows that no child updates have no source in the gather list: start from zero
+    hipError_t me = hipMemsetAsync(D.bigv, 0, (size_t) (D.batch * nrhs * D.bv_size) * sizeof(double), st);
+    if (me != hipSuccess) return me;
+    hipLaunchKernelGGL(k_fwd_big_gather, dim3(4, pl.by, g.count), dim3(256), 0, st, D.sdesc, g.first, D.fasm_src,
+                       D.fasm_tgt, D.flong_src, D.cv, X, D.bigv, nrhs, D.cv_size * (long long) nrhs, D.n * (long long) nrhs, D.bv_size);
+    CS3_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+template <int KIND>
+static hipError_t launch_fwd_big_chunk(const DeviceFactor &D, const LaunchGroup &g, double *X, int nrhs, int c, hipStream_t st)
+{
+    const BigSweepPlan pl = big_sweep_plan(D, g, nrhs);
+    const long long xs = D.n * (long long) nrhs, cvs = D.cv_size * (long long) nrhs;
+    if (pl.wide)
+        hipLaunchKernelGGL((k_fwd_big_step<KIND, BIG_CW>), dim3(pl.slices, pl.by, g.count), dim3(256), 0, st, D.sdesc,
+                           g.first, c * pl.cw, D.pool, D.cv, X, D.bigv, nrhs, D.pool_size, cvs, xs, D.bv_size);
+    else if (pl.multi)
+        hipLaunchKernelGGL((k_fwd_big_step_multi<KIND>), dim3(pl.slices, pl.by_multi, g.count), dim3(256), 0, st, D.sdesc,
+                           g.first, c * pl.cw, D.pool, D.cv, X, D.bigv, nrhs, D.pool_size, cvs, xs, D.bv_size);
+    else
+        hipLaunchKernelGGL((k_fwd_big_step<KIND, SOLVE_BW>), dim3(pl.slices, pl.by, g.count), dim3(256), 0, st, D.sdesc,
+                           g.first, c * pl.cw, D.pool, D.cv, X, D.bigv, nrhs, D.pool_size, cvs, xs, D.bv_size);
+    CS3_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+template <int KIND>
+static hipError_t launch_bwd_big_pre(const DeviceFactor &D, const LaunchGroup &g, double *X, int nrhs, hipStream_t st)
+{
+    const BigSweepPlan pl = big_sweep_plan(D, g, nrhs);
+    const size_t lds = (size_t) std::max(1, g.max_r) * sizeof(double);
+    hipLaunchKernelGGL((k_bwd_big_init<KIND>), dim3(2, pl.by, g.count), dim3(256), lds, st, D.sdesc, g.first,
+                       D.st_idx, D.pool, X, D.bigv, nrhs, D.pool_size, D.n * (long long) nrhs, D.bv_size);
+    CS3_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+template <int KIND>
+static hipError_t launch_bwd_big_chunk(const DeviceFactor &D, const LaunchGroup &g, double *X, int nrhs, int c, hipStream_t st)
+{
+    const BigSweepPlan pl = big_sweep_plan(D, g, nrhs);
+    const long long xs = D.n * (long long) nrhs;
+    if (pl.wide)
+        hipLaunchKernelGGL((k_bwd_big_step<KIND, BIG_CW>), dim3(pl.slices, pl.by, g.count), dim3(256), 0, st, D.sdesc,
+                           g.first, c, D.pool, X, D.bigv, nrhs, D.pool_size, xs, D.bv_size);
+    else if (pl.multi)
+        hipLaunchKernelGGL((k_bwd_big_step_multi<KIND>), dim3(pl.slices, pl.by_multi, g.count), dim3(256), 0, st, D.sdesc,
+                           g.first, c, D.pool, X, D.bigv, nrhs, D.pool_size, xs, D.bv_size);
+    else
+        hipLaunchKernelGGL((k_bwd_big_step<KIND, SOLVE_BW>), dim3(pl.slices, pl.by, g.count), dim3(256), 0, st, D.sdesc,
+                           g.first, c, D.pool, X, D.bigv, nrhs, D.pool_size, xs, D.bv_size);
+    CS3_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
 constexpr int RHS_LANES_MIN = 16;          // from this many right-hand sides on, SK_SMALL fronts run lane = right-hand side
 
 template <int KIND, int RMAX>
@@ -2012,51 +2104,11 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
                                    D.pool, X, nrhs, D.pool_size, xs);
         }
     } else if (g.cls == SK_BIG) {
-        const unsigned by = (unsigned) (D.batch * nrhs);
-        const bool wide = (long long) D.batch * nrhs < 8;      // few right-hand sides: latency-bound, two blocks per launch
-        const bool multi = nrhs >= BIG_KT;                      // many right-hand sides: BIG_KT of them per workgroup
-        const unsigned by_multi = (unsigned) (D.batch * ((nrhs + BIG_KT - 1) / BIG_KT));
-        const int cw = wide ? BIG_CW : SOLVE_BW;
-        const int nchunk = (g.max_w + cw - 1) / cw;
-        const int slices = std::max(1, (g.max_r + 63) / 64);
-        if (forward) {
-            // rows that no child updates have no source in the gather list: start from zero
-            hipError_t me = hipMemsetAsync(D.bigv, 0, (size_t) (D.batch * nrhs * D.bv_size) * sizeof(double), st);
-            if (me != hipSuccess) return me;
-            hipLaunchKernelGGL(k_fwd_big_gather, dim3(4, by, g.count), dim3(256), 0, st, D.sdesc, g.first, D.fasm_src,
-                               D.fasm_tgt, D.flong_src, D.cv, X, D.bigv, nrhs, cvs, xs, D.bv_size);
-            CS3_LAUNCH_CHECK();
-            for (int c = 0; c < nchunk; ++c) {
-                if (wide)
-                    hipLaunchKernelGGL((k_fwd_big_step<KIND, BIG_CW>), dim3(slices, by, g.count), dim3(256), 0, st, D.sdesc,
-                                       g.first, c * cw, D.pool, D.cv, X, D.bigv, nrhs, D.pool_size, cvs, xs, D.bv_size);
-                else if (multi)
-                    hipLaunchKernelGGL((k_fwd_big_step_multi<KIND>), dim3(slices, by_multi, g.count), dim3(256), 0, st, D.sdesc,
-                                       g.first, c * cw, D.pool, D.cv, X, D.bigv, nrhs, D.pool_size, cvs, xs, D.bv_size);
-                else
-                    hipLaunchKernelGGL((k_fwd_big_step<KIND, SOLVE_BW>), dim3(slices, by, g.count), dim3(256), 0, st, D.sdesc,
-                                       g.first, c * cw, D.pool, D.cv, X, D.bigv, nrhs, D.pool_size, cvs, xs, D.bv_size);
-                CS3_LAUNCH_CHECK();
-            }
-        } else {
-            const size_t lds = (size_t) std::max(1, g.max_r) * sizeof(double);
-            hipLaunchKernelGGL((k_bwd_big_init<KIND>), dim3(2, by, g.count), dim3(256), lds, st, D.sdesc, g.first,
-                               D.st_idx, D.pool, X, D.bigv, nrhs, D.pool_size, xs, D.bv_size);
-            CS3_LAUNCH_CHECK();
-            for (int c = 0; c < nchunk; ++c) {
-                if (wide)
-                    hipLaunchKernelGGL((k_bwd_big_step<KIND, BIG_CW>), dim3(slices, by, g.count), dim3(256), 0, st, D.sdesc,
-                                       g.first, c, D.pool, X, D.bigv, nrhs, D.pool_size, xs, D.bv_size);
-                else if (multi)
-                    hipLaunchKernelGGL((k_bwd_big_step_multi<KIND>), dim3(slices, by_multi, g.count), dim3(256), 0, st, D.sdesc,
-                                       g.first, c, D.pool, X, D.bigv, nrhs, D.pool_size, xs, D.bv_size);
-                else
-                    hipLaunchKernelGGL((k_bwd_big_step<KIND, SOLVE_BW>), dim3(slices, by, g.count), dim3(256), 0, st, D.sdesc,
-                                       g.first, c, D.pool, X, D.bigv, nrhs, D.pool_size, xs, D.bv_size);
-                CS3_LAUNCH_CHECK();
-            }
-        }
-        return hipSuccess;
+        const BigSweepPlan pl = big_sweep_plan(D, g, nrhs);
+        hipError_t e = forward ? launch_fwd_big_pre(D, g, X, nrhs, st) : launch_bwd_big_pre<KIND>(D, g, X, nrhs, st);
+        for (int c = 0; e == hipSuccess && c < pl.nchunk; ++c)
+            e = forward ? launch_fwd_big_chunk<KIND>(D, g, X, nrhs, c, st) : launch_bwd_big_chunk<KIND>(D, g, X, nrhs, c, st);
+        return e;
     } else {
         dim3 grid((unsigned) g.count, (unsigned) D.batch, (unsigned) nrhs);
         const size_t lds = (size_t) (g.max_r + 1 + SOLVE_BW) * sizeof(double);
@@ -2163,11 +2215,57 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
         }
         return hipSuccess;
     };
+    // The last level, when it is one group of wide big fronts (the dense root): its forward sweep does not wait
+    // for the end of its factorisation either.  Column block b of the factor is final in F after block launch
+    // b + 1 (k_big_step), so chunk c of the sweep follows on fj.aux as soon as its blocks are home, while the
+    // later blocks are still being factorised.
+    const LaunchGroup *rootf = nullptr, *roots = nullptr;
+    static const bool pipe_root = !(getenv("CS3_NO_ROOT_PIPE") && getenv("CS3_NO_ROOT_PIPE")[0] == '1');
+    if (pipe_root && nlevels >= 2 && fork_level == nlevels - 2) {
+        int nf = 0, ns = 0;
+        for (const LaunchGroup &g : fgroups) if (g.level == nlevels - 1) { ++nf; rootf = &g; }
+        for (const LaunchGroup &g : sgroups) if (g.level == nlevels - 1) { ++ns; roots = &g; }
+        if (nf != 1 || ns != 1 || rootf->cls != FC_BIG || roots->cls != SK_BIG || rootf->count != roots->count)
+            rootf = roots = nullptr;
+    }
     hipEvent_t swept = nullptr;
+    int root_rest = 0;                             // first chunk of the root's sweep that is still to do after the join
     for (size_t f0 = 0; f0 < fgroups.size(); ) {
         const int level = fgroups[f0].level;
         size_t f1 = f0;
         while (f1 < fgroups.size() && fgroups[f1].level == level) ++f1;
+        if (rootf && level == nlevels - 1) {
+            const BigSweepPlan pl = big_sweep_plan(D, *roots, nrhs);
+            const int nblk = big_group_blocks(*rootf), cwb = pl.cw / BIG_NB;
+            if ((e = launch_big_gather(D, *rootf, st)) != hipSuccess) return e;
+            if ((e = launch_fwd_big_pre(D, *roots, X, nrhs, fj.aux)) != hipSuccess) return e;
+            // ONE release (every cross-stream edge costs the block chain about 10 us): the first k chunks go to
+            // fj.aux after block launch k * cwb, k the largest count that the remaining launches still cover;
+            // the other chunks follow on st after the join.
+            int k = 0;
+            while (k < pl.nchunk && (k + 1) * cwb <= nblk && nblk - (k + 1) * cwb >= k + 1) ++k;
+            for (int blk = 0; blk <= nblk; ++blk) {
+                e = (D.kind == CS3_LU) ? launch_big_block<CS3_LU>(D, *rootf, blk, inv_tol, st)
+                                       : launch_big_block<CS3_CHOLESKY>(D, *rootf, blk, inv_tol, st);
+                if (e != hipSuccess) return e;
+                if (k > 0 && blk == k * cwb) {                         // blocks 0 .. blk - 1 are home
+                    hipEvent_t home;
+                    if ((e = fj.event(&home)) != hipSuccess) return e;
+                    if ((e = hipEventRecord(home, st)) != hipSuccess) return e;
+                    if ((e = hipStreamWaitEvent(fj.aux, home, 0)) != hipSuccess) return e;
+                    for (int c = 0; c < k; ++c) {
+                        e = (D.kind == CS3_LU) ? launch_fwd_big_chunk<CS3_LU>(D, *roots, X, nrhs, c, fj.aux)
+                                               : launch_fwd_big_chunk<CS3_CHOLESKY>(D, *roots, X, nrhs, c, fj.aux);
+                        if (e != hipSuccess) return e;
+                    }
+                }
+            }
+            root_rest = k;
+            if ((e = fj.event(&swept)) != hipSuccess) return e;           // replaces the join recorded at the fork
+            if ((e = hipEventRecord(swept, fj.aux)) != hipSuccess) return e;
+            f0 = f1;
+            continue;
+        }
         e = run_level(fgroups, f0, f1, st, fj, true, [&](const LaunchGroup &g, hipStream_t s) {
             return (D.kind == CS3_LU) ? launch_front_group<CS3_LU>(D, g, inv_tol, s)
                                       : launch_front_group<CS3_CHOLESKY>(D, g, inv_tol, s);
@@ -2185,7 +2283,14 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
         f0 = f1;
     }
     if (swept && (e = hipStreamWaitEvent(st, swept, 0)) != hipSuccess) return e;
-    return sweep(fork_level + 1, nlevels, st);
+    if (!rootf) return sweep(fork_level + 1, nlevels, st);
+    const BigSweepPlan pl = big_sweep_plan(D, *roots, nrhs);
+    for (int c = root_rest; c < pl.nchunk; ++c) {
+        e = (D.kind == CS3_LU) ? launch_fwd_big_chunk<CS3_LU>(D, *roots, X, nrhs, c, st)
+                               : launch_fwd_big_chunk<CS3_CHOLESKY>(D, *roots, X, nrhs, c, st);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_prologue(const DeviceFactor &D, const double *ax_src, const double *x_src, int nrhs, hipStream_t st)

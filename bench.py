@@ -120,8 +120,7 @@ def main():
     def step():
         # one step = numeric refactorisation + full solve: cs3_factor_solve_dev, one graph in which the
         # forward sweep of the finished tree levels runs beside the factorisation of the tail
-        d_x.copy_(d_b)
-        F.factor_solve_dev(d_ax.data_ptr(), d_x.data_ptr(), args.rhs, tol, sh)
+        F.factor_solve_bx_dev(d_ax.data_ptr(), d_b.data_ptr(), d_x.data_ptr(), args.rhs, tol, sh)     # x = A \ b, b kept
 
     def split_step(events=None):
         # the same work as two calls; only here can the phases be bracketed by events

@@ -72,6 +72,7 @@ def lib():
         L.cs3_factor_dev.argtypes = [vp, vp, C.c_double, vp]
         L.cs3_factor_status.argtypes = [vp, vp]
         L.cs3_factor_solve_dev.argtypes = [vp, vp, C.c_double, vp, I64, vp]
+        L.cs3_factor_solve_bx_dev.argtypes = [vp, vp, C.c_double, vp, vp, I64, vp]
         for f in (L.cs3_solve, L.cs3_lsolve, L.cs3_usolve):
             f.argtypes = [vp, _f64p, I64]
         for f in (L.cs3_solve_dev, L.cs3_lsolve_dev, L.cs3_usolve_dev):
@@ -258,6 +259,10 @@ class Factorization:
     def factor_solve_dev(self, ax_ptr, x_ptr, k=1, tol=0.0, stream=0):
         """(Re)factorise and solve in one call (cs_lusol on resident data); X is overwritten."""
         _check(lib().cs3_factor_solve_dev(self._h, C.c_void_p(ax_ptr), tol, C.c_void_p(x_ptr), k, C.c_void_p(stream)))
+
+    def factor_solve_bx_dev(self, ax_ptr, b_ptr, x_ptr, k=1, tol=0.0, stream=0):
+        """The same out of place: right-hand sides at b_ptr stay as they are, solutions go to x_ptr."""
+        _check(lib().cs3_factor_solve_bx_dev(self._h, C.c_void_p(ax_ptr), tol, C.c_void_p(b_ptr), C.c_void_p(x_ptr), k, C.c_void_p(stream)))
 
     def factor_status(self, stream=0):
         _check(lib().cs3_factor_status(self._h, C.c_void_p(stream)))

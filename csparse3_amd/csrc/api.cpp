@@ -253,7 +253,7 @@ int run_solve(cs3_handle h, double *x_dev, long long k, int mode, hipStream_t st
 }
 
 // numeric factorisation and full solve in one graph; the forward sweep runs beside the factorisation
-int run_factor_solve(cs3_handle h, const double *ax_dev, double *x_dev, long long k, double tol, hipStream_t st)
+int run_factor_solve(cs3_handle h, const double *ax_dev, const double *b_dev, double *x_dev, long long k, double tol, hipStream_t st)
 {
     if (k < 1 || k > INT_MAX) { set_error("factor_solve: bad number of right-hand sides"); return CS3_ERR_ARG; }
     int rc = ensure_rhs_capacity(h, k);
@@ -261,7 +261,7 @@ int run_factor_solve(cs3_handle h, const double *ax_dev, double *x_dev, long lon
     DeviceFactor &D = h->D;
     const int nrhs = (int) k;
     const double inv_tol = (tol > 0.0) ? 1.0 / tol : HUGE_VAL;
-    CS3_HIP(launch_prologue(D, ax_dev, x_dev, nrhs, st));
+    CS3_HIP(launch_prologue(D, ax_dev, b_dev, nrhs, st));      // right-hand sides are read from b_dev, the solution goes to x_dev
     if (h->use_graph) {
         if (h->fused_inv_tol != inv_tol) {
             for (auto &kv : h->fused_graphs) (void) hipGraphExecDestroy(kv.second);
@@ -445,7 +445,15 @@ int cs3_factor_solve_dev(cs3_handle h, const double *Ax_dev, double tol, double 
     int rc = guard(h); if (rc) return rc;
     if ((!Ax_dev && h->S.nnzA > 0) || !X_dev) { set_error("cs3_factor_solve_dev: null argument"); return CS3_ERR_ARG; }
     if ((rc = ensure_device(h))) return rc;
-    return run_factor_solve(h, Ax_dev, X_dev, k, tol, (hipStream_t) stream);
+    return run_factor_solve(h, Ax_dev, X_dev, X_dev, k, tol, (hipStream_t) stream);
+}
+
+int cs3_factor_solve_bx_dev(cs3_handle h, const double *Ax_dev, double tol, const double *B_dev, double *X_dev, int64_t k, void *stream)
+{
+    int rc = guard(h); if (rc) return rc;
+    if ((!Ax_dev && h->S.nnzA > 0) || !B_dev || !X_dev) { set_error("cs3_factor_solve_bx_dev: null argument"); return CS3_ERR_ARG; }
+    if ((rc = ensure_device(h))) return rc;
+    return run_factor_solve(h, Ax_dev, B_dev, X_dev, k, tol, (hipStream_t) stream);
 }
 
 int cs3_factor_status(cs3_handle h, void *stream)

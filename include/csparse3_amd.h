@@ -111,6 +111,9 @@ int cs3_factor_dev(cs3_handle h, const double *Ax_dev, double tol, void *stream)
  * for bit; the forward sweep of a tree level runs beside the factorisation of the next level, so
  * the call is shorter than the two in sequence.  Status via cs3_factor_status. */
 int cs3_factor_solve_dev(cs3_handle h, const double *Ax_dev, double tol, double *X_dev, int64_t k, void *stream);
+/* The same, out of place: right-hand sides read from B_dev, solutions written to X_dev (x = A^-1 b without
+ * the copy of b that the in-place form needs when b is kept). */
+int cs3_factor_solve_bx_dev(cs3_handle h, const double *Ax_dev, double tol, const double *B_dev, double *X_dev, int64_t k, void *stream);
 /* Deferred status of the last cs3_factor_dev / cs3_factor_solve_dev (synchronises the stream). */
 int cs3_factor_status(cs3_handle h, void *stream);
 

@@ -419,6 +419,10 @@ def test_factor_solve_fused_equals_factor_then_solve(gpu, case, nrhs):
             F.factor_solve_dev(d_ax.data_ptr(), x_fused.data_ptr(), nrhs, 1e-3, sh)
             F.factor_status(sh)
             assert torch.equal(x_fused, x_split)
+        d_b = torch.from_numpy(b).to(dev); x_out = torch.zeros_like(d_b)       # out of place: b untouched
+        F.factor_solve_bx_dev(d_ax.data_ptr(), d_b.data_ptr(), x_out.data_ptr(), nrhs, 1e-3, sh)
+        F.factor_status(sh)
+        assert torch.equal(x_out, x_split) and torch.equal(d_b, torch.from_numpy(b).to(dev))
         Lx_a = F.factors()[2]
     with gpu.Factorization(m, n, Ap, Ai, kind) as G:   # fused as the very first call on a handle
         x0 = torch.from_numpy(b).to(dev)

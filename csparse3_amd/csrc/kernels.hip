@@ -1466,7 +1466,8 @@ k_fwd_big_step_multi(const SolveDesc *__restrict__ sd, int first, int kb,
         ta.load(L, r, kb, bw);
         double vi[BIG_KT];
 #pragma unroll
-        for (int q = 0; q < BIG_KT; ++q) vi[q] = load_if(v0 + (long long) q * bv_size, kb + lane, lane < bw && q < nlive);
+        for (int q = 0; q < BIG_KT; ++q)                               // a dead slot reads slot 0: past nrhs there is no vector
+            vi[q] = load_if(v0 + (long long) (q < nlive ? q : 0) * bv_size, kb + lane, lane < bw && q < nlive);
         ta.template solve_multi<BIG_KT>(vi, bw);
 #pragma unroll
         for (int q = 0; q < BIG_KT; ++q) y[q][lane] = (lane < bw) ? vi[q] : 0.0;
@@ -1529,7 +1530,8 @@ k_bwd_big_step_multi(const SolveDesc *__restrict__ sd, int first, int chunk_from
         ta.load(L, r, kb, bw);
         double vi[BIG_KT];
 #pragma unroll
-        for (int q = 0; q < BIG_KT; ++q) vi[q] = load_if(v0 + (long long) q * bv_size, kb + lane, lane < bw && q < nlive);
+        for (int q = 0; q < BIG_KT; ++q)                               // a dead slot reads slot 0: past nrhs there is no vector
+            vi[q] = load_if(v0 + (long long) (q < nlive ? q : 0) * bv_size, kb + lane, lane < bw && q < nlive);
         ta.template solve_multi<BIG_KT>(vi, bw);
 #pragma unroll
         for (int q = 0; q < BIG_KT; ++q) y[q][lane] = (lane < bw) ? vi[q] : 0.0;

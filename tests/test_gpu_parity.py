@@ -504,3 +504,40 @@ def test_many_rhs_batch_of_matrices(gpu):
         for i in range(3):
             A = csc_to_scipy(m, n, Ap, Ai, AX[i])
             assert np.abs(A @ X[i] - B[i]).max() <= 1e-11 * n
+
+
+@pytest.mark.parametrize("nd", [70, 150, 300, 421])
+@pytest.mark.parametrize("nrhs", [1, 9])
+@pytest.mark.parametrize("chol", [False, True])
+def test_fused_root_pipeline_block_and_chunk_combinations(gpu, nd, nrhs, chol):
+    """The fused call releases part of the root's forward sweep while the root is still being factorised; how many
+    chunks depends on the root's width (blocks of 32, chunks of 128 or 64 columns).  Every combination must equal
+    factor-then-solve bit for bit."""
+    import torch
+    import scipy.sparse as sp
+    m, n, Ap, Ai, Ax = synth.dense_block_matrix(n=nd + 400, nd=nd, seed=nd)
+    kind = gpu.CS3_LU
+    if chol:
+        A = sp.csc_matrix((Ax, Ai, Ap), shape=(n, n))
+        S = (A + A.T).tocsc(); S.sort_indices()
+        Ap, Ai, Ax = S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.copy()
+        kind = gpu.CS3_CHOLESKY
+    b = np.random.default_rng(nd + nrhs).standard_normal((n, nrhs) if nrhs > 1 else n)
+    dev = torch.device("cuda", 0)
+    sh = torch.cuda.current_stream().cuda_stream
+    d_ax = torch.from_numpy(Ax).to(dev)
+    d_b = torch.from_numpy(b).to(dev)
+    with gpu.Factorization(m, n, Ap, Ai, kind) as F:
+        assert F.info.max_front >= nd
+        x_split = d_b.clone()
+        F.factor_dev(d_ax.data_ptr(), 1e-3, sh)
+        F.solve_dev(x_split.data_ptr(), nrhs, sh)
+        F.factor_status(sh)
+        for _ in range(2):
+            x_fused = torch.zeros_like(d_b)
+            F.factor_solve_bx_dev(d_ax.data_ptr(), d_b.data_ptr(), x_fused.data_ptr(), nrhs, 1e-3, sh)
+            F.factor_status(sh)
+            assert torch.equal(x_fused, x_split)
+    A = csc_to_scipy(m, n, Ap, Ai, Ax)
+    x = x_split.cpu().numpy()
+    assert np.abs(A @ x - b).max() <= 1e-10 * max(1.0, np.abs(b).max()) * n

@@ -1461,16 +1461,19 @@ k_fwd_big_step_multi(const SolveDesc *__restrict__ sd, int first, int kb,
         const int jj = wv * 16 + j;
         ls[j] = load_if(L, (long long) row + (long long) (kb + jj) * r, row < r && jj < bw);
     }
-    if (wv == 0) {
+    {                                               // every wave solves the triangle for BIG_KT / 4 of the vectors
+        constexpr int QW = BIG_KT / 4;
         BlockTriangle<KIND, true> ta;
         ta.load(L, r, kb, bw);
-        double vi[BIG_KT];
+        double vi[QW];
 #pragma unroll
-        for (int q = 0; q < BIG_KT; ++q)                               // a dead slot reads slot 0: past nrhs there is no vector
-            vi[q] = load_if(v0 + (long long) (q < nlive ? q : 0) * bv_size, kb + lane, lane < bw && q < nlive);
-        ta.template solve_multi<BIG_KT>(vi, bw);
+        for (int u = 0; u < QW; ++u) {                   // a dead slot reads slot 0: past nrhs there is no vector
+            const int q = wv * QW + u;
+            vi[u] = load_if(v0 + (long long) (q < nlive ? q : 0) * bv_size, kb + lane, lane < bw && q < nlive);
+        }
+        ta.template solve_multi<QW>(vi, bw);
 #pragma unroll
-        for (int q = 0; q < BIG_KT; ++q) y[q][lane] = (lane < bw) ? vi[q] : 0.0;
+        for (int u = 0; u < QW; ++u) y[wv * QW + u][lane] = (lane < bw) ? vi[u] : 0.0;
     }
     __syncthreads();
     if (blockIdx.x == 0 && tid < bw)
@@ -1525,16 +1528,19 @@ k_bwd_big_step_multi(const SolveDesc *__restrict__ sd, int first, int chunk_from
                                                : (long long) (kb + jj) + (long long) row * r;
         us[j] = load_if(L, off, row < kb && jj < bw);
     }
-    if (wv == 0) {
+    {                                               // every wave solves the triangle for BIG_KT / 4 of the vectors
+        constexpr int QW = BIG_KT / 4;
         BlockTriangle<KIND, false> ta;
         ta.load(L, r, kb, bw);
-        double vi[BIG_KT];
+        double vi[QW];
 #pragma unroll
-        for (int q = 0; q < BIG_KT; ++q)                               // a dead slot reads slot 0: past nrhs there is no vector
-            vi[q] = load_if(v0 + (long long) (q < nlive ? q : 0) * bv_size, kb + lane, lane < bw && q < nlive);
-        ta.template solve_multi<BIG_KT>(vi, bw);
+        for (int u = 0; u < QW; ++u) {                   // a dead slot reads slot 0: past nrhs there is no vector
+            const int q = wv * QW + u;
+            vi[u] = load_if(v0 + (long long) (q < nlive ? q : 0) * bv_size, kb + lane, lane < bw && q < nlive);
+        }
+        ta.template solve_multi<QW>(vi, bw);
 #pragma unroll
-        for (int q = 0; q < BIG_KT; ++q) y[q][lane] = (lane < bw) ? vi[q] : 0.0;
+        for (int u = 0; u < QW; ++u) y[wv * QW + u][lane] = (lane < bw) ? vi[u] : 0.0;
     }
     __syncthreads();
     if (blockIdx.x == 0 && tid < bw)

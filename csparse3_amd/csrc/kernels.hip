@@ -315,19 +315,6 @@ front_lds_body(const FrontDesc &d, int first, double *F,
 #undef CS3_STAMP
 }
 
-template <int KIND, int THREADS, int TX, int RI, int RJ>
-__global__ void __launch_bounds__(THREADS)
-k_front_lds(const FrontDesc *__restrict__ fdesc, int first,
-            const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
-            const double *__restrict__ ax_all, double *__restrict__ pool_all,
-            long long nnz_a, long long pool_stride, double inv_tol, int *status, long long *tbuf)
-{
-    extern __shared__ __attribute__((aligned(16))) double F[];
-    const long long t_start = tbuf ? (long long) __builtin_amdgcn_s_memtime() : 0;
-    const FrontDesc d = fdesc[first + blockIdx.x];
-    front_lds_body<KIND, THREADS, TX, RI, RJ>(d, first, F, asm_src, asm_tgt, long_src, ax_all, pool_all, nnz_a,
-                                              pool_stride, inv_tol, status, tbuf, t_start);
-}
 
 // ---------------------------------------------- front owned by ONE wave ----
 // Fronts of order r <= NC <= 64: lane i keeps ROW i of the front in NC registers, so a pivot
@@ -517,8 +504,8 @@ k_big_gather(const FrontDesc *__restrict__ fdesc, int first,
 //   * keep_unscaled (block-ROW tiles of LU): the block lanes hold D' and the stacked lanes columns of
 //     the tile; the multiplier t_k / u_kk drives the updates but the entry that is kept is t_k
 //     itself, which is U(k, column) for the unit-lower solve  L_D u = t.
-template <int KIND>
-__device__ __forceinline__ void eliminate32(double (&d)[BIG_NB], bool keep_unscaled)
+template <int KIND, int NBK>
+__device__ __forceinline__ void eliminate_block(double (&d)[NBK], bool keep_unscaled)
 {
     const int lane = threadIdx.x & 63;
     const bool stacked = lane >= 32;
@@ -526,12 +513,12 @@ __device__ __forceinline__ void eliminate32(double (&d)[BIG_NB], bool keep_unsca
     double dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
     double rp = fast_rcp(dg);
 #pragma unroll
-    for (int k = 0; k < BIG_NB; ++k) {
+    for (int k = 0; k < NBK; ++k) {
         const bool below = lane > k;
         const double l = below ? d[k] * rp : 0.0;
         if (below && !(keep_unscaled && stacked)) d[k] = l;
         if (KIND == CS3_CHOLESKY && lane == k) d[k] = (piv > 0.0) ? dg : -1.0;
-        if (k + 1 < BIG_NB) {
+        if (k + 1 < NBK) {
             if (KIND == CS3_LU) d[k + 1] -= l * bcast_lane(d[k + 1], k);
             else { const double lj = bcast_lane(d[k], k + 1); if (lane >= k + 1) d[k + 1] -= l * lj; }
             piv = bcast_lane(d[k + 1], k + 1);
@@ -539,11 +526,166 @@ __device__ __forceinline__ void eliminate32(double (&d)[BIG_NB], bool keep_unsca
             rp = fast_rcp(dg);
         }
 #pragma unroll
-        for (int j = k + 2; j < BIG_NB; ++j) {
+        for (int j = k + 2; j < NBK; ++j) {
             if (KIND == CS3_LU) d[j] -= l * bcast_lane(d[j], k);
             else { const double lj = bcast_lane(d[k], j); if (lane >= j) d[j] -= l * lj; }      // L(j, k): lane j, register k
         }
     }
+}
+
+template <int KIND>
+__device__ __forceinline__ void eliminate32(double (&d)[BIG_NB], bool keep_unscaled) { eliminate_block<KIND, BIG_NB>(d, keep_unscaled); }
+
+// Fronts of order 65 .. 136: the front image lives in LDS (one workgroup of 8 waves per front) and is
+// factorised 32 pivots at a time with the same two tools as the big fronts, without leaving the workgroup:
+//   1. eliminate32 -- waves 0..3 stack 32 rows of the block column under the 32 x 32 diagonal block D, waves
+//      4..7 stack 32 columns of the block row under D'; the stacked lanes come out as the solved panels;
+//   2. the trailing part of the image gets  F22 -= L21 U12  by v_mfma_f64_16x16x4 with both operands read straight
+//      from the LDS image (column-major with an odd leading dimension: conflict-free either way).
+// NBK = pivots per block: 32, or 16 for a launch whose fronts have at most 16 pivots (the elimination runs all NBK
+// identity-padded steps).  The previous kernel for this class kept 5 x 9 register tiles and crossed the LDS and two block barriers for
+// every pivot (about 3 k cycles per pivot; this one: about 0.6 k).
+template <int KIND, int NBK>
+__global__ void __launch_bounds__(512)
+k_front_block(const FrontDesc *__restrict__ fdesc, int first,
+              const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
+              const double *__restrict__ ax_all, double *__restrict__ pool_all,
+              long long nnz_a, long long pool_stride, double inv_tol, int *status, long long *tbuf)
+{
+    extern __shared__ __attribute__((aligned(16))) double F[];
+    const long long t_start = tbuf ? (long long) __builtin_amdgcn_s_memtime() : 0;
+#define CS3_STAMP(p) do { if (tbuf && threadIdx.x == 0) tbuf[(long long) (first + blockIdx.x) * 8 + (p)] = (long long) __builtin_amdgcn_s_memtime() - t_start; } while (0)
+    const FrontDesc d = fdesc[first + blockIdx.x];
+    const double *ax = ax_all + (long long) blockIdx.y * nnz_a;
+    double *pool = pool_all + (long long) blockIdx.y * pool_stride;
+    const int r = d.r, w = d.w, nb = r - w;
+    const int ld = r | 1;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, li = lane & 31;
+    const bool stacked = lane >= 32;
+
+    // ---- assemble: F = sum of sources (A entries, children's contribution blocks)
+    CS3_STAMP(0);
+    for (int i = tid; i < r * ld + 1; i += 512) F[i] = 0.0;
+    __syncthreads();
+    CS3_STAMP(1);
+    gather_front(d.asm_begin, d.asm_count >> 6, wv * GATHER_UNROLL, 8 * GATHER_UNROLL, asm_src, asm_tgt, long_src,
+                 [&](int q) -> const double * { return (q >= 0) ? pool + q : ax + ~q; },
+                 [&](int t, double v) { F[t] = v; });
+    __syncthreads();
+    CS3_STAMP(2);
+
+    bool bad = false;
+    int bad_col = 0;
+    for (int kb = 0; kb < w; kb += NBK) {
+        const int bw = min(NBK, w - kb), ke = kb + bw, nrem = r - ke;
+        // ---- 1. the block and its panels: one stacked elimination per wave (at most 128 rows / columns lie
+        // beyond a block: the analysis sends the rare front that would need a fifth group to the big-front class)
+        const bool row_wave = wv >= 4;                      // D' with columns of the block row stacked (LU only)
+        const int grp = wv & 3, s0 = ke + 32 * grp, si = s0 + li;      // my stacked row (column for a row wave)
+        const bool owner = wv == 0;                         // keeps the factored block
+        const bool active = !(KIND == CS3_CHOLESKY && row_wave) && (owner || s0 < r);
+        double e[NBK];
+        if (active) {
+            // entry j of my row: one LDS read at base + j * stride.  Block lanes: D (D' for a row wave), identity past
+            // bw; stacked lanes: my row of the block column (my column of the block row for a row wave)
+            const int line = stacked ? si : kb + li;
+            const int base = row_wave ? kb + line * ld : line + kb * ld, stride = row_wave ? 1 : ld;
+            const bool mine = stacked ? si < r : li < bw;
+#pragma unroll
+            for (int j = 0; j < NBK; ++j) {
+                const double v = F[(mine && j < bw) ? base + j * stride : 0];
+                e[j] = (mine && j < bw) ? v : ((!stacked && li == j) ? 1.0 : 0.0);
+            }
+        }
+        __syncthreads();                                    // everybody has read D before wave 0 writes its factors back
+        if (active) {
+            eliminate_block<KIND, NBK>(e, row_wave);
+            // pivots and multipliers, then home into the image
+#pragma unroll
+            for (int j = 0; j < NBK; ++j) {
+                if (j < bw) {
+                    const double v = e[j], av = fabs(v);
+                    if (!stacked) {
+                        if (owner && li < bw) {
+                            bool rej;
+                            if (KIND == CS3_LU) {
+                                const double lim = (li == j) ? 1.0e300 : inv_tol;
+                                rej = ((li >= j) & !(av <= lim)) | ((li == j) & !(av > 0.0));
+                            } else {
+                                rej = (li == j) & !(v > 0.0);
+                            }
+                            if (rej && !bad) { bad = true; bad_col = kb + j; }
+                            F[(kb + li) + (kb + j) * ld] = v;
+                        }
+                    } else if (si < r) {
+                        if (!row_wave) {
+                            if (KIND == CS3_LU && !(av <= inv_tol) && !bad) { bad = true; bad_col = kb + j; }
+                            F[si + (kb + j) * ld] = v;
+                        } else {
+                            F[(kb + j) + si * ld] = v;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 2. trailing update by MFMA, operands from the image: 16 x 16 tiles of F22 dealt to the 8 waves
+        if (nrem > 0) {
+            const int nt = (nrem + 15) / 16, mi = lane & 15, mq = lane >> 4;
+            for (int t = wv; t < nt * nt; t += 8) {
+                const int ti = t % nt, tj = t / nt;             // tile rows ke + 16 ti.., columns ke + 16 tj..
+                if (KIND == CS3_CHOLESKY && ti < tj) continue;
+                const int i = ke + 16 * ti + mi;                // my row (B operand / output lanes % 16)
+                double4_t acc;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int c = ke + 16 * tj + mq + 4 * v;
+                    acc[v] = (i < r && c < r) ? F[i + c * ld] : 0.0;
+                }
+                const int ca = ke + 16 * tj + mi;               // A operand: U(kb + k, column ca) (Cholesky: L(ca, kb + k))
+#pragma unroll
+                for (int k0 = 0; k0 < NBK; k0 += 4) {
+                    if (k0 < bw) {
+                        const int k = kb + k0 + mq;
+                        const bool kin = k0 + mq < bw;
+                        const double au = (kin && ca < r) ? ((KIND == CS3_LU) ? F[k + ca * ld] : F[ca + k * ld]) : 0.0;
+                        const double bl = (kin && i < r) ? -F[i + k * ld] : 0.0;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(au, bl, acc, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int c = ke + 16 * tj + mq + 4 * v;
+                    if (i < r && c < r) F[i + c * ld] = acc[v];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    CS3_STAMP(3);
+    CS3_STAMP(4);
+    if (bad) flag_column(status, d.c0 + bad_col);
+    // ---- store: L panel, U panel, contribution block
+    double *L = pool + d.lpan;
+    double *U = pool + d.upan;
+    double *cb = pool + d.cb;
+    const bool has_parent = d.parent >= 0;
+    for (int e = tid; e < r * w; e += 512) {                    // L panel, column-major r x w
+        const int i = e % r, j = e / r;
+        if (KIND == CS3_LU || i >= j) L[e] = F[i + j * ld];
+    }
+    if (KIND == CS3_LU)
+        for (int e = tid; e < w * nb; e += 512) {               // U panel: pivot rows contiguous (u_sk = 1, u_sj = w)
+            const int i = e % w, j = e / w;
+            U[(long long) j * d.u_sj + (long long) i * d.u_sk] = F[i + (w + j) * ld];
+        }
+    if (has_parent)
+        for (int e = tid; e < nb * nb; e += 512) {
+            const int i = e % nb, j = e / nb;
+            if (KIND == CS3_LU || i >= j) cb[e] = F[(w + i) + (w + j) * ld];
+        }
+    CS3_STAMP(5);
+#undef CS3_STAMP
 }
 
 // Blocked right-looking LU / Cholesky with ONE launch per block step.
@@ -1880,7 +2022,9 @@ static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g
     case FC_R64:
         hipLaunchKernelGGL((k_front_mix<KIND>), grid, dim3(256), lds, st, CS3_FRONT_ARGS); break;
     default:
-        hipLaunchKernelGGL((k_front_lds<KIND, 512, 32, 5, 9>), grid, dim3(512), lds, st, CS3_FRONT_ARGS); break;
+        if (g.max_w <= 16) hipLaunchKernelGGL((k_front_block<KIND, 16>), grid, dim3(512), lds, st, CS3_FRONT_ARGS);
+        else hipLaunchKernelGGL((k_front_block<KIND, 32>), grid, dim3(512), lds, st, CS3_FRONT_ARGS);
+        break;
     }
 #undef CS3_FRONT_ARGS
     CS3_LAUNCH_CHECK();
@@ -1892,12 +2036,12 @@ hipError_t prepare_kernels()
     // the largest LDS-resident class needs more than the default 64 KiB of dynamic LDS
     const int big = 160 * 1024;
     hipError_t e;
-    e = hipFuncSetAttribute((const void *) k_front_lds<CS3_LU, 512, 32, 5, 9>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void *) k_front_lds<CS3_CHOLESKY, 512, 32, 5, 9>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    if (e != hipSuccess) return e;
+    const void *block_fns[] = {(const void *) k_front_block<CS3_LU, 16>, (const void *) k_front_block<CS3_LU, 32>,
+                               (const void *) k_front_block<CS3_CHOLESKY, 16>, (const void *) k_front_block<CS3_CHOLESKY, 32>};
+    for (const void *f : block_fns) {
+        e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        if (e != hipSuccess) return e;
+    }
     const void *solve_fns[] = {
         (const void *) k_fwd_blk<CS3_LU>, (const void *) k_fwd_blk<CS3_CHOLESKY>,
         (const void *) k_bwd_blk<CS3_LU>, (const void *) k_bwd_blk<CS3_CHOLESKY>,

@@ -109,11 +109,13 @@ double seconds_since(std::chrono::steady_clock::time_point t0)
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
-int front_class(i64 r, bool split_small)
+int front_class(i64 r, i64 w, bool split_small)
 {
     if (r <= 32 && split_small) return FC_R32;   // batched handles: one wave per front, its own launch
     if (r <= 64) return FC_R64;       // one launch: k_front_mix (one wave for r <= 32, 16 x 16 threads above)
-    if (r <= 136) return FC_LDS;      // (136*137 + 4*136 + 6) doubles = 153 KB of the 160 KB LDS
+    // k_front_block: the image fits the LDS ((136*137 + 4*136 + 6) doubles = 153 KB of 160 KB) and the rows below
+    // the first pivot block fit four stacked groups of 32
+    if (r <= 136 && r - std::min<i64>(w, 16) <= 128) return FC_LDS;
     return FC_BIG;
 }
 
@@ -392,7 +394,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     S.max_front = 0; S.max_width = 0; S.flops = 0.0;
     for (i32 s = 0; s < ns; ++s) {                   // panels of the LDS-resident fronts
         const i64 w = width(s), r = order_r(s), nb = r - w;
-        S.sn_class[s] = front_class(r, S.batch >= 8);
+        S.sn_class[s] = front_class(r, w, S.batch >= 8);
         S.cv_off[s] = cvoff; cvoff += nb;
         S.rel_ptr[s + 1] = S.rel_ptr[s] + nb;
         S.max_front = std::max(S.max_front, r);

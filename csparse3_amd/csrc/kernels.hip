@@ -346,8 +346,14 @@ front_wave_body(const FrontDesc &d, int first, double *F,
                  [&](int t, double v) { F[t] = v; });
     __syncthreads();
     CS3_STAMP(2);
-    if (threadIdx.x >= 64) return;
-    const int lane = threadIdx.x;
+    const bool coop = blockDim.x > 64;          // helper waves stay for the store pass
+    if (threadIdx.x >= 64 && !coop) return;
+    const int lane = threadIdx.x & 63;
+    bool bad = false;
+    int bad_col = 0;
+    const bool has_parent = d.parent >= 0;
+    const bool live = lane < r;
+    if (threadIdx.x < 64) {
     double row[NC];
     {
         const int li = lane < r ? lane : 0;             // unconditional LDS reads, then select
@@ -357,10 +363,6 @@ front_wave_body(const FrontDesc &d, int first, double *F,
             row[j] = (lane < r && j < r) ? v : 0.0;
         }
     }
-    const bool has_parent = d.parent >= 0;
-    const bool live = lane < r;
-    bool bad = false;
-    int bad_col = 0;
     CS3_STAMP(3);
     // Elimination only: column k of the registers is column k of the front for the whole loop (no
     // stores, no checks, no shifting inside it); the reciprocal of the next pivot is issued right
@@ -397,6 +399,7 @@ front_wave_body(const FrontDesc &d, int first, double *F,
         }
     }
     CS3_STAMP(4);
+    if (!coop) {
     // checks and stores, one pass.  Pool offsets fit 32 bits (analysis refuses larger pools): column j of
     // my row goes to the L panel (j < w), else to the U panel (my row is a pivot row) or the contribution block.
     {
@@ -425,6 +428,37 @@ front_wave_body(const FrontDesc &d, int first, double *F,
                 const int off = in_l ? lp + j * r : base2 + j * stride2;
                 const bool ok = (in_l ? live : ok2) & tri;
                 if (ok) pool[off] = v;
+            }
+        }
+    }
+    } else if (live) {                          // my row back into the image, column by column (conflict-free)
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+            if (j < r) F[lane + j * ld] = row[j];
+    }
+    }                                           // (wave 0)
+    if (coop) {
+        // checks and stores by all four waves from the image: a quarter of the store instructions per wave
+        __syncthreads();
+        const int nth = blockDim.x;
+        for (int e = threadIdx.x; e < r * r; e += nth) {
+            const int i = e % r, j = e / r;
+            const double v = F[i + j * ld], av = fabs(v);
+            const bool tri = (KIND == CS3_LU) | (i >= j);
+            if (j < w) {
+                bool rej;
+                if (KIND == CS3_LU) {
+                    const double lim = (i == j) ? 1.0e300 : inv_tol;
+                    rej = ((i >= j) & !(av <= lim)) | ((i == j) & !(av > 0.0));
+                } else {
+                    rej = (i == j) & !(v > 0.0);
+                }
+                if (rej && (!bad || j < bad_col)) { bad = true; bad_col = j; }
+                if (tri) pool[(int) d.lpan + i + j * r] = v;
+            } else if (i < w) {
+                if (KIND == CS3_LU) pool[(int) d.upan + i * d.u_sk + (j - w) * d.u_sj] = v;
+            } else if (has_parent && tri) {
+                pool[(int) d.cb + (i - w) + (j - w) * nb] = v;
             }
         }
     }

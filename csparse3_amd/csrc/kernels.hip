@@ -747,6 +747,9 @@ k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__res
     const long long t_start = tbuf ? (long long) __builtin_amdgcn_s_memtime() : 0;
 #define CS3_BSTAMP(p) do { if (tbuf && kb == 64 && blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0) \
         tbuf[(long long) (first + blockIdx.z / batch) * 8 + (p)] = (long long) __builtin_amdgcn_s_memtime() - t_start; } while (0)
+    // ... and the block-row tile (0, 1) of the same step: slots 6 (eliminated) and 7 (stored)
+#define CS3_BSTAMP_ROW(p) do { if (tbuf && kb == 64 && blockIdx.x == 0 && blockIdx.y == 1 && threadIdx.x == 0) \
+        tbuf[(long long) (first + blockIdx.z / batch) * 8 + (p)] = (long long) __builtin_amdgcn_s_memtime() - t_start; } while (0)
     __shared__ double As[BIG_NB][64 + 1];       // As[k][i] = L(row0 + i, kp + k)
     __shared__ double Bs[BIG_NB][64 + 1];       // Bs[k][j] = U(kp + k, col0 + j)
     __shared__ double Ad[BIG_NB][BIG_NB + 1];   // Ad[k][i] = L(kb + i, kp + k)
@@ -899,6 +902,7 @@ k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__res
     }
     eliminate32<KIND>(e, row_tile);
     CS3_BSTAMP(4);
+    CS3_BSTAMP_ROW(6);
     if (diag_tile) {                                // park the factored block, check its pivots
         double *db = dbuf + (long long) (kb / BIG_NB) * (BIG_NB * BIG_NB);
         if (lane < bw) {
@@ -937,7 +941,9 @@ k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__res
         }
     }
     CS3_BSTAMP(5);
+    CS3_BSTAMP_ROW(7);
 #undef CS3_BSTAMP
+#undef CS3_BSTAMP_ROW
 }
 
 

@@ -38,4 +38,4 @@ for l in range(int(lvl.max()) + 1):
 big = np.flatnonzero((fr > 136) & (out[:, 5] > 0))
 for j in big:
     print("big front r,w =", fr[j], fw[j], "step kb=64 tile(1,0) cycles since kernel start: loads issued %d, staged %d, updated %d, "
-          "D/T in LDS %d, D factored %d, panel solved+stored %d" % tuple(out[j, :6]))
+          "D/T in LDS %d, D factored %d, panel solved+stored %d; block-row tile (0,1): eliminated %d, stored %d" % tuple(out[j, :8]))

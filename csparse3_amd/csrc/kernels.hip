@@ -2436,7 +2436,18 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
             // the other chunks follow on st after the join.
             int k = 0;
             while (k < pl.nchunk && (k + 1) * cwb <= nblk && nblk - (k + 1) * cwb >= k + 1) ++k;
+            static const bool absorb = !(getenv("CS3_NO_ABSORB") && getenv("CS3_NO_ABSORB")[0] == '1');
             for (int blk = 0; blk <= nblk; ++blk) {
+                if (absorb && k > 0 && blk == k * cwb) {
+                    // the side branch (sweep of the lower levels, the root's gather) finished long ago: the block chain
+                    // absorbs it here, so that the chunks released below hang off the chain alone -- a chunk with two
+                    // parents in different queues keeps a barrier pending in the side queue for hundreds of
+                    // microseconds, and the chain's dispatches slow down while it does
+                    hipEvent_t pre;
+                    if ((e = fj.event(&pre)) != hipSuccess) return e;
+                    if ((e = hipEventRecord(pre, fj.aux)) != hipSuccess) return e;
+                    if ((e = hipStreamWaitEvent(st, pre, 0)) != hipSuccess) return e;
+                }
                 e = (D.kind == CS3_LU) ? launch_big_block<CS3_LU>(D, *rootf, blk, inv_tol, st)
                                        : launch_big_block<CS3_CHOLESKY>(D, *rootf, blk, inv_tol, st);
                 if (e != hipSuccess) return e;

@@ -1,19 +1,25 @@
 #!/usr/bin/env python3
-"""Headline benchmark: numeric LU + lsolve/usolve on the 50k power-grid Jacobian.
+"""Headline benchmark: numeric LU + lsolve/usolve on the 50k power-grid Jacobian, plus the two sharding
+configurations of BASELINE.json on the same JSON line.
 
     python bench.py --gpus N --steps K --warmup W
 
-One step = one pass of the hot path over one matrix that is already resident
-in HBM: numeric refactorisation (assembly + multifrontal LU, symbolic analysis
-reused) followed by one full solve (permute, lsolve, usolve, permute) with
-`--rhs` right-hand sides.  Workload = BASELINE.json configs[2] (50k x 50k,
-~500k nnz, 1 RHS).  With N > 1 every rank owns its own matrix (same pattern,
-different values -- independent Jacobians, no data-path collective): weak
-scaling, value = all ranks' units / max-over-ranks time.
+`value` (the driver's number) = BASELINE.json configs[2]: one step = one pass of the hot path over one matrix
+already resident in HBM -- numeric refactorisation (assembly + multifrontal LU, symbolic analysis reused) and
+one full solve (permute, lsolve, usolve, permute) with `--rhs` right-hand sides, as ONE fused call.  A single
+factorisation never spans GPUs (north_star), so with N > 1 every rank owns its own matrix (same pattern,
+different values, no data-path collective): weak scaling, value = all ranks' units / max-over-ranks time.
+units per step = (nnz(L) + nnz(U)) * (1 + rhs)  (SURVEY.md section 8d metrics (i) + (ii)).
 
-units per step = (nnz(L) + nnz(U)) * (1 + rhs): every factor entry is produced
-once by the factorisation and read once per right-hand side by the sweeps
-(SURVEY.md section 8d metric (i) + (ii)).
+`configs` (same line) = the two configurations that DO shard, at their own sizes:
+  "4": the same 50k matrix, factor once + 1024 right-hand sides.  N = 1: all 1024 on one GPU.  N > 1:
+       csparse3_amd.shard.solve_many_rhs over the process group -- rank 0 factorises, ONE broadcast of the factor
+       panels, RHS slabs of 1024 / N columns fanned out, independent sweeps, ONE gather -- with factor /
+       broadcast / scatter / solve / gather timed apart.
+  "5": 512 independent 5k x 5k SPD matrices sharing a pattern, Cholesky factor + 1 solve each (fused call).
+       N = 1: all 512 on one GPU.  N > 1: shard.solve_many_matrices, 512 / N per rank, no collective on the
+       data path, one gather of the solutions.
+Each carries ms, units/s, algorithmic bytes (SURVEY.md section 8d formulas) and the HBM fraction.
 
 Prints ONE JSON line on rank 0.
 """
@@ -39,28 +45,263 @@ def csc_matvec_np(n, Ap, Ai, Ax, x):
     return y
 
 
+def _median_time(fn, reps, budget_s):
+    """One warm-up, then up to `reps` timed runs (at least 5 unless the budget runs out): median seconds."""
+    fn()
+    ts = []
+    t_all = time.perf_counter()
+    while len(ts) < reps and (len(ts) < 5 or time.perf_counter() - t_all < budget_s):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all > 2.5 * budget_s:
+            break
+    return float(np.median(ts)), len(ts)
+
+
 def cpu_baseline(n, Ap, Ai, Ax, q, b, nnz_lu, rhs, budget_s=12.0):
-    """The oracle (a port: the reference has no factor/solve code) on the host, 1 thread."""
+    """the oracle (a port -- the reference has no factor/solve code) on this host,
+    1 thread, compiled here with -O3 -march=native, median of >= 5 runs after a warm-up; B3: SciPy SuperLU as an
+    independent comparator when SciPy is importable."""
     from oracle import oracle as orc
-    orc.lib()
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
+    flags = orc.use_native() or "gcc -O2 (portable build: the native build failed)"
+    st = {}
+
+    def one():
         Lp, Li, Lx, Up, Ui, Ux, pinv = orc.csc_lu_f(n, n, Ap, Ai, Ax, q, 1e-3)
         for _ in range(rhs):
             x = np.empty(n)
             x[pinv] = b                       # x = P b
             orc.csc_lsolve_f(n, Lp, Li, Lx, x)
             orc.csc_usolve_f(n, Up, Ui, Ux, x)
-        reps += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or reps >= 200:
-            break
-    units = nnz_lu * (1 + rhs) * reps
-    return {"value": units / el, "unit": "nnz/s", "cores": 1, "kind": "port",
-            "sample": "%d x (orc_lu with the same pivot order + %d lsolve/usolve) on the same 50k matrix, "
-                      "%.1f s, gcc -O2" % (reps, rhs, el),
-            "ms_per_step": 1e3 * el / reps}
+        st["x"] = x
+
+    t, reps = _median_time(one, 15, budget_s)
+    out = {"value": nnz_lu * (1 + rhs) / t, "unit": "nnz/s", "cores": 1, "kind": "port",
+           "sample": "median of %d x (orc_lu with the same pivot order + %d lsolve/usolve) on the same 50k matrix after "
+                     "1 warm-up, %s" % (reps, rhs, flags),
+           "ms_per_step": 1e3 * t}
+    try:
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as spl
+        A = sp.csc_matrix((Ax, Ai, Ap), shape=(n, n))
+        st2 = {}
+
+        def slu():
+            lu = spl.splu(A, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.001, options=dict(SymmetricMode=True))
+            for _ in range(rhs):
+                st2["x"] = lu.solve(b)
+            st2["nnz"] = lu.L.nnz + lu.U.nnz
+
+        ts, r2 = _median_time(slu, 7, budget_s / 2)
+        out["comparator"] = {"what": "scipy.sparse.linalg.splu (SuperLU, MMD_AT_PLUS_A, 1 thread) factor + %d solve" % rhs,
+                             "ms_per_step": 1e3 * ts, "runs": r2, "nnz_lu": int(st2["nnz"]),
+                             "value": nnz_lu * (1 + rhs) / ts, "unit": "nnz/s (this bench's unit count over SuperLU's time)"}
+    except Exception as e:                                      # SciPy is never a dependency
+        out["comparator"] = {"error": repr(e)}
+    return out
+
+
+def cpu_threads_baseline(kind, payload, budget_s=8.0):
+    """the oracle over all host cores (one Python thread per core; ctypes releases the
+    GIL), on a bounded sample of config 4 (RHS columns) or config 5 (matrices)."""
+    import concurrent.futures as cf
+    from oracle import oracle as orc
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    orc.lib()
+    if kind == "rhs":
+        n, Lp, Li, Lx, Up, Ui, Ux, pinv, B = payload
+        k = B.shape[1]
+
+        def work(j):
+            x = np.empty(n)
+            x[pinv] = B[:, j]
+            orc.csc_lsolve_f(n, Lp, Li, Lx, x)
+            orc.csc_usolve_f(n, Up, Ui, Ux, x)
+            return x[0]
+
+        def run():
+            with cf.ThreadPoolExecutor(cores) as ex:
+                list(ex.map(work, range(k)))
+        t, reps = _median_time(run, 5, budget_s)
+        return {"seconds": t, "cores": cores, "sample": "%d RHS columns, oracle lsolve + usolve, %d threads, median of %d"
+                % (k, cores, reps), "units": k}
+    n, Ap, Ai, AX, q = payload
+    nm = AX.shape[0]
+
+    def workm(i):
+        pinv = orc.csc_pinv(q)
+        _, _, Cp, Ci, _ = orc.csc_symperm(n, Ap, Ai, None, pinv)
+        parent = orc.csc_etree_f(n, Cp, Ci)
+        cnt = orc.csc_counts_f(n, Cp, Ci, parent, orc.csc_post_f(n, parent))
+        cp = np.zeros(n + 1, dtype=np.int32); cp[1:] = np.cumsum(cnt)
+        Lp, Li, Lx = orc.csc_chol_f(n, Ap, Ai, AX[i], pinv, parent, cp)
+        x = np.ones(n)
+        orc.csc_lsolve_f(n, Lp, Li, Lx, x)
+        orc.csc_ltsolve_f(n, Lp, Li, Lx, x)
+        return x[0]
+
+    def runm():
+        with cf.ThreadPoolExecutor(cores) as ex:
+            list(ex.map(workm, range(nm)))
+    t, reps = _median_time(runm, 5, budget_s)
+    return {"seconds": t, "cores": cores, "sample": "%d matrices, oracle cs_chol (symbolic included) + 2 sweeps, %d threads, "
+            "median of %d" % (nm, cores, reps), "units": nm}
+
+
+# ------------------------------------------------------------------------------------------ the two sharding legs --
+
+def _sync(dist, world):
+    import torch
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+
+
+def _max_over_ranks(dist, world, dev, vals):
+    import torch
+    if world == 1:
+        return [float(v) for v in vals]
+    t = torch.tensor(vals, dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(v) for v in t.tolist()]
+
+
+def leg_config4(args, dist, rank, world, dev, comm_dev, host_baseline):
+    """Factor once + 1024 right-hand sides on the 50k matrix; sharded over the ranks when world > 1."""
+    import torch
+    from csparse3_amd import shard, synth, csc_hip as hip
+    k = args.c4_rhs
+    m, n, Ap, Ai, Ax = synth.grid_jacobian(n=args.n, seed=args.n)
+    be = shard.HipBackend(m, n, Ap, Ai, kind=hip.CS3_LU, device=dev)
+    info = be.F.info
+    nnz_l, nnz_u = int(info.nnz_l), int(info.nnz_u)
+    B = synth.grid_rhs(n, k, seed=1024) if rank == 0 else None
+    reps = args.c4_reps
+    phases = []
+    X = None
+    for it in range(reps + 1):                                   # first pass = warm-up (graph capture, allocations)
+        tm = {}
+        _sync(dist, world)
+        t0 = time.perf_counter()
+        X = shard.solve_many_rhs(be, Ax, B, tol=1e-3, timings=tm, sync=lambda: _sync(dist, world))
+        _sync(dist, world)
+        tm["total"] = time.perf_counter() - t0
+        if it > 0:
+            phases.append(tm)
+    keys = ["factor", "broadcast", "scatter", "solve", "gather", "total"]
+    med = [float(np.median([p.get(kk, 0.0) for p in phases])) for kk in keys]
+    med = _max_over_ranks(dist, world, comm_dev, med)
+    out = None
+    if rank == 0:
+        x0 = X[:, 0].cpu().numpy()
+        res = csc_matvec_np(n, Ap, Ai, Ax, x0) - B[:, 0]
+        rel = float(np.abs(res).max() / np.abs(B[:, 0]).max())
+        if not rel < 1e-9:
+            raise RuntimeError("config 4: residual %.3e" % rel)
+        t = dict(zip(keys, med))
+        nnz_lu = nnz_l + nnz_u
+        bytes_solve = (12 * nnz_l + 4 * (n + 1) + 16 * n * k) + (12 * nnz_u + 4 * (n + 1) + 16 * n * k) + 2 * 8 * n * k
+        out = {"workload": "configs[3]: %dx%d Jacobian, factor once + %d RHS lsolve/usolve%s"
+                           % (n, n, k, "" if world == 1 else ", RHS slabs over %d ranks (factor broadcast + gather)" % world),
+               "rhs": k, "n_gpus": world, "reps": reps,
+               "solve_ms": 1e3 * t["solve"], "total_ms": 1e3 * t["total"],
+               "phases_ms": {kk: 1e3 * t[kk] for kk in keys},
+               "solve_nnz_per_s": nnz_lu * k / t["solve"], "job_nnz_per_s": nnz_lu * k / t["total"],
+               "algorithmic_bytes": bytes_solve,
+               "solve_GBs": bytes_solve / t["solve"] / 1e9,
+               "frac": bytes_solve / t["solve"] / 1e9 / HBM_PEAK_GBS / world,
+               "frac_note": "solve phase: algorithmic bytes / max-over-ranks solve time / (n_gpus x 8 TB/s)",
+               "factor_bytes_broadcast": int(info.factor_bytes),
+               "rel_residual": rel}
+        if host_baseline:
+            try:
+                from oracle import oracle as orc
+                Lp, Li, Lx, Up, Ui, Ux = be.F.factors()
+                o = be.F.ordering()
+                cb = cpu_threads_baseline("rhs", (n, Lp, Li, Lx, Up, Ui, Ux, o["pinv"], np.ascontiguousarray(B[:, :64])))
+                out["cpu_baseline"] = {"value": nnz_lu * cb["units"] / cb["seconds"], "unit": "nnz/s", "cores": cb["cores"],
+                                       "kind": "port", "sample": cb["sample"]}
+            except Exception as e:
+                out["cpu_baseline"] = {"error": repr(e)}
+    be.F.close()
+    return out
+
+
+def leg_config5(args, dist, rank, world, dev, comm_dev, host_baseline):
+    """512 SPD 5k x 5k matrices, one pattern: Cholesky factor + solve, sharded by matrix when world > 1."""
+    import torch
+    from csparse3_amd import shard, synth, csc_hip as hip
+    nmat, n5 = args.c5_mats, args.c5_n
+    ei, ej = synth.spd_grid_pattern(n5, seed=5000)
+    lo, hi = shard.shard_range(nmat, world, rank)
+    m, n, Ap, Ai, _ = synth.spd_grid_matrix(n5, ei, ej, seed=5000)
+    # every rank builds the values of ITS slice only (seeded: matrix i has seed 5000 + i)
+    AX_mine = np.stack([synth.spd_grid_matrix(n5, ei, ej, seed=5000 + i)[4] for i in range(lo, hi)]) if hi > lo \
+        else np.zeros((0, int(Ap[n])))
+    rng = np.random.default_rng(0)
+    B_all = rng.standard_normal((nmat, n, 1))
+    be_cache = {}
+
+    def make_backend(batch):
+        if batch not in be_cache:
+            be_cache[batch] = shard.HipBackend(m, n, Ap, Ai, kind=hip.CS3_CHOLESKY, batch=batch, device=dev)
+        return be_cache[batch]
+
+    reps = args.c5_reps
+    phases = []
+    X = None
+    for it in range(reps + 1):
+        tm = {}
+        _sync(dist, world)
+        t0 = time.perf_counter()
+        X = shard.solve_many_matrices(make_backend, AX_mine, B_all, tol=0.0, timings=tm, sync=lambda: _sync(dist, world),
+                                      local_values=True, total=nmat)
+        _sync(dist, world)
+        tm["total"] = time.perf_counter() - t0
+        if it > 0:
+            phases.append(tm)
+    keys = ["upload", "factor_solve", "gather", "total"]
+    med = [float(np.median([p.get(kk, 0.0) for p in phases])) for kk in keys]
+    med = _max_over_ranks(dist, world, comm_dev, med)
+    out = None
+    be = make_backend(hi - lo) if hi > lo else None
+    if rank == 0:
+        info = be.F.info
+        nnz_l = int(info.nnz_l)
+        t = dict(zip(keys, med))
+        nnz_tril = (int(Ap[n]) - n) // 2 + n
+        per = (12 * nnz_tril + 12 * nnz_l + 8 * (n + 1)) + 2 * (12 * nnz_l + 4 * (n + 1) + 16 * n) + 2 * 8 * n
+        i = 3 % nmat
+        Ax_i = synth.spd_grid_matrix(n5, ei, ej, seed=5000 + i)[4]
+        res = csc_matvec_np(n, Ap, Ai, Ax_i, X[i, :, 0].cpu().numpy()) - B_all[i, :, 0]
+        rel = float(np.abs(res).max() / np.abs(B_all[i]).max())
+        if not rel < 1e-9:
+            raise RuntimeError("config 5: residual %.3e" % rel)
+        out = {"workload": "configs[4]: %d SPD %dx%d matrices, one pattern, Cholesky factor + 1-RHS solve each%s"
+                           % (nmat, n, n, "" if world == 1 else ", %d per rank over %d ranks (no data-path collective)" % (hi - lo, world)),
+               "matrices": nmat, "n": n, "nnz_l": nnz_l, "levels": int(info.nlevels), "n_gpus": world, "reps": reps,
+               "factor_solve_ms": 1e3 * t["factor_solve"], "total_ms": 1e3 * t["total"],
+               "phases_ms": {kk: 1e3 * t[kk] for kk in keys},
+               "matrices_per_s": nmat / t["factor_solve"], "nnz_per_s": nmat * 3 * nnz_l / t["factor_solve"],
+               "algorithmic_bytes": per * nmat,
+               "GBs": per * nmat / t["factor_solve"] / 1e9,
+               "frac": per * nmat / t["factor_solve"] / 1e9 / HBM_PEAK_GBS / world,
+               "frac_note": "factor + solve phase: algorithmic bytes / max-over-ranks time / (n_gpus x 8 TB/s)",
+               "rel_residual": rel}
+        if host_baseline:
+            try:
+                q = be.F.ordering()["q"]
+                cb = cpu_threads_baseline("mats", (n, Ap, Ai, AX_mine[:32], q))
+                out["cpu_baseline"] = {"value": 3 * nnz_l * cb["units"] / cb["seconds"], "unit": "nnz/s", "cores": cb["cores"],
+                                       "kind": "port", "sample": cb["sample"],
+                                       "matrices_per_s": cb["units"] / cb["seconds"]}
+            except Exception as e:
+                out["cpu_baseline"] = {"error": repr(e)}
+    for b in be_cache.values():
+        b.F.close()
+    return out
 
 
 def main():
@@ -71,6 +312,12 @@ def main():
     ap.add_argument("--n", type=int, default=50000)
     ap.add_argument("--rhs", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--configs", default="4,5", help="sharding legs to run beside the headline ('' = none)")
+    ap.add_argument("--c4-rhs", type=int, default=1024)
+    ap.add_argument("--c4-reps", type=int, default=10)
+    ap.add_argument("--c5-mats", type=int, default=512)
+    ap.add_argument("--c5-n", type=int, default=5000)
+    ap.add_argument("--c5-reps", type=int, default=10)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse N > 1 on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
@@ -91,6 +338,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
     if world > 1:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -167,7 +415,7 @@ def main():
     t_solve_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -179,6 +427,22 @@ def main():
     rel_res = float(np.abs(res).max() / (np.abs(b1).max() + 1e-300))
     if not rel_res < 1e-9:
         raise SystemExit("bench: solution check failed, relative residual %.3e" % rel_res)
+    q_order = F.ordering()["q"]
+    F.close()
+
+    # ---- the two sharding configurations (every rank takes part; failures are reported, never fatal to `value`)
+    legs = {}
+    want = [c for c in args.configs.split(",") if c]
+    host_bl = (not args.no_cpu_baseline) and world == 1
+    for name, fn in (("4", leg_config4), ("5", leg_config5)):
+        if name not in want:
+            continue
+        try:
+            legs[name] = fn(args, dist, rank, world, dev, comm_dev, host_bl)
+        except Exception as e:                                   # noqa: BLE001
+            legs[name] = {"error": repr(e)}
+            if world > 1:
+                raise                                            # a rank that left a collective would hang the others
 
     if rank == 0:
         # algorithmic bytes: int32 index + f64 value per entry, each array once
@@ -187,11 +451,14 @@ def main():
         bytes_solve = (12 * nnz_l + 4 * (n + 1) + 16 * n * args.rhs) + \
                       (12 * nnz_u + 4 * (n + 1) + 16 * n * args.rhs) + 2 * 8 * n * args.rhs
         achieved = bytes_factor / (t_factor_ms * 1e-3) / 1e9
-        traffic = None                               # PMC bytes per factorisation, from the committed profile
-        try:
+        traffic, traffic_src = None, None            # PMC bytes per factorisation: NOT measured by this run (rocprofv3
+        try:                                         # collects them in separate passes); read from the committed profile
             import glob
             tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
-            traffic = json.load(open(tf))["factor"]["hbm_bytes_corrected"] if args.n == 50000 else None
+            if args.n == 50000:
+                traffic = json.load(open(tf))["factor"]["hbm_bytes_corrected"]
+                traffic_src = "profiles/" + os.path.basename(tf) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
+                              "FETCH doubled as the guide prescribes); not collected by this run"
         except Exception:
             traffic = None
         out = {
@@ -212,14 +479,15 @@ def main():
                        "n": n, "nnz_a": nnz_a, "nnz_l": nnz_l, "nnz_u": nnz_u, "rhs": args.rhs,
                        "supernodes": int(info.nsuper), "levels": int(info.nlevels),
                        "max_front": int(info.max_front), "ordering": "amd(A+A')",
-                       "parallelism": "independent matrices per rank, no collective"},
+                       "parallelism": "independent matrices per rank, no collective (a single factorisation stays on "
+                                      "one GPU); the sharding configurations are under `configs`"},
             "roofline": {"bound": "hbm",
-                         "kernel": "numeric factorisation = one hipGraph of k_front_mix / k_front_lds / k_big_gather / "
-                                   "k_big_step launches (per tree level; one per 32 pivots of a big front)",
+                         "kernel": "numeric factorisation = one hipGraph of k_front_mix / k_front_block / k_big_gather / "
+                                   "k_big_step launches (per tree level; one per block step of a big front)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "frac_of_measured_peak": achieved / HBM_MEASURED_GBS,
-                         "traffic": traffic,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": bytes_factor,
                          "avg_launch_ms": t_factor_ms,
                          "measured": "HIP events around the stand-alone factorisation graph, %d launches right after "
@@ -232,14 +500,13 @@ def main():
                        "solve_hbm_GBs": bytes_solve / (t_solve_ms * 1e-3) / 1e9,
                        "symbolic_s": float(info.t_order_s + info.t_symbolic_s),
                        "rel_residual": rel_res},
+            "configs": legs,
         }
         if not args.no_cpu_baseline and world == 1:
-            q = F.ordering()["q"]
-            out["cpu_baseline"] = cpu_baseline(n, Ap, Ai, Ax, q, b1, nnz_lu, args.rhs)
+            out["cpu_baseline"] = cpu_baseline(n, Ap, Ai, Ax, q_order, b1, nnz_lu, args.rhs)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    F.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -9,6 +9,8 @@ are star-imported from the backend module exactly as csc.py:34-41 does, so
 `from csparse3_amd.csc import *` exposes csc_lu_f, csc_lsolve_f, ... next to
 the class.
 """
+import hashlib
+
 import numpy as np
 
 from csparse3_amd import __config__
@@ -90,8 +92,20 @@ class CscMat:
         return _k.csc_norm(self.n, self.indptr, self.data)
 
     # ---- new: factor / solve
+    def _pattern_fingerprint(self):
+        """(m, n, nnz, digest of indptr / indices): the symbolic analysis is valid for exactly this pattern.
+        indptr / indices may be changed in place or reassigned between two lu() calls; comparing the digest
+        (a few ms at 500k entries) is what makes "mutate, then refactor" safe."""
+        n = self.n
+        indptr = np.ascontiguousarray(self.indptr[:n + 1], dtype=np.int32)
+        nnz = int(indptr[n]) if n > 0 else 0
+        h = hashlib.blake2b(digest_size=16)
+        h.update(indptr.tobytes())
+        h.update(np.ascontiguousarray(self.indices[:nnz], dtype=np.int32).tobytes())
+        return self.m, n, nnz, h.digest()
+
     def _analysis(self, kind, order, q):
-        key = (kind, order, None if q is None else bytes(np.asarray(q, dtype=np.int32)))
+        key = (kind, order, None if q is None else bytes(np.asarray(q, dtype=np.int32)), self._pattern_fingerprint())
         f = self._factorization
         if f is None or f[0] != key:
             if f is not None:

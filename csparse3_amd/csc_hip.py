@@ -92,7 +92,7 @@ def lib():
         L.cs3_coo_to_csc.argtypes = [I64, I64, I64, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p]
         L.cs3_csc_norm.argtypes = [I64, _i32p, _f64p, C.POINTER(C.c_double)]
         L.cs3_csc_add.argtypes = [I64, I64, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p, C.c_double, C.c_double, _i32p, _i32p, _f64p]
-        L.cs3_csc_sub_matrix.argtypes = [I64, _i32p, _i32p, _f64p, _i32p, I64, _i32p, I64, _i32p, _i32p, _f64p]
+        L.cs3_csc_sub_matrix.argtypes = [I64, _i32p, _i32p, _f64p, _i32p, I64, _i32p, I64, _i32p, _i32p, _f64p, I64]
         L.cs3_find_islands.argtypes = [I64, _i32p, _i32p, _i32p]
         _lib = L
     return _lib
@@ -431,8 +431,9 @@ def csc_sub_matrix(Am, Anz, Ap, Ai, Ax, rows, cols):
     index is that function's running match counter, not the position of the row in `rows`."""
     Ap, Ai, Ax, rows, cols = _i32(Ap), _i32(Ai), _f64(Ax), _i32(rows), _i32(cols)
     n = len(Ap) - 1
-    Bp = np.empty(len(cols) + 1, dtype=np.int32); Bi = np.empty(max(Anz, 1), dtype=np.int32); Bx = np.zeros(max(Anz, 1), dtype=np.float64)
-    _check(lib().cs3_csc_sub_matrix(n, _pi(Ap), _pi(Ai), _pf(Ax), _pi(rows), len(rows), _pi(cols), len(cols), _pi(Bp), _pi(Bi), _pf(Bx)))
+    cap = max(Anz, 1)                                    # what the reference allocates (csc_numba.py:476-478)
+    Bp = np.empty(len(cols) + 1, dtype=np.int32); Bi = np.empty(cap, dtype=np.int32); Bx = np.zeros(cap, dtype=np.float64)
+    _check(lib().cs3_csc_sub_matrix(n, _pi(Ap), _pi(Ai), _pf(Ax), _pi(rows), len(rows), _pi(cols), len(cols), _pi(Bp), _pi(Bi), _pf(Bx), cap))
     nz = int(Bp[len(cols)])
     return nz, Bp, Bi[:nz].copy(), Bx[:nz].copy()
 

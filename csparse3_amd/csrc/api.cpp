@@ -67,9 +67,38 @@ void drop_solve_graphs(cs3_handle h)
     h->fused_graphs.clear();
 }
 
+// Frees every HBM allocation of the handle (ensure_device's error path and cs3_free).
+void release_device(cs3_handle h)
+{
+    DeviceFactor &D = h->D;
+    if (h->factor_graph) { (void) hipGraphExecDestroy(h->factor_graph); h->factor_graph = nullptr; }
+    drop_solve_graphs(h);
+    if (h->cap_stream) { (void) hipStreamDestroy(h->cap_stream); h->cap_stream = nullptr; }
+    h->fj.destroy();
+    void **ptrs[] = {(void **) &D.fdesc, (void **) &D.st_idx, (void **) &D.asm_src, (void **) &D.asm_tgt, (void **) &D.long_src,
+                     (void **) &D.sdesc, (void **) &D.fasm_src, (void **) &D.fasm_tgt, (void **) &D.flong_src, (void **) &D.rl_pairs,
+                     (void **) &D.q, (void **) &D.ax, (void **) &D.pool, (void **) &D.dbuf, (void **) &D.tbuf, (void **) &D.bigv,
+                     (void **) &D.cv, (void **) &D.xp, (void **) &D.status, (void **) &h->d_lmap, (void **) &h->d_umap,
+                     (void **) &h->d_lx, (void **) &h->d_ux};
+    for (void **p : ptrs) if (*p) { (void) hipFree(*p); *p = nullptr; }
+    D.nrhs_cap = 0;
+    h->on_device = false;
+}
+
+int ensure_device_impl(cs3_handle h);
+
+// Uploads the analysis and allocates the numeric state; a failure half way leaves nothing behind, so a
+// retry starts from scratch instead of allocating on top of the leaked buffers.
 int ensure_device(cs3_handle h)
 {
     if (h->on_device) return CS3_OK;
+    const int rc = ensure_device_impl(h);
+    if (rc != CS3_OK) release_device(h);
+    return rc;
+}
+
+int ensure_device_impl(cs3_handle h)
+{
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         set_error("no HIP device visible: the numeric path runs on the GPU only (there is no CPU fallback)");
@@ -127,6 +156,7 @@ int ensure_device(cs3_handle h)
     CS3_HIP(hipMalloc((void **) &D.dbuf, std::max<size_t>(1, (size_t) (D.batch * D.dbuf_size)) * sizeof(double)));
     CS3_HIP(hipMalloc((void **) &D.ax, std::max<size_t>(1, (size_t) (D.batch * D.nnz_a)) * sizeof(double)));
     CS3_HIP(hipMalloc((void **) &D.status, sizeof(int)));
+    CS3_HIP(hipMemset(D.status, 0x7f, sizeof(int)));      // "clean": a handle that only imports factors never runs a prologue
     if (const char *pf = std::getenv("CS3_PROFILE")) {
         if (pf[0] == '1') {
             CS3_HIP(hipMalloc((void **) &D.tbuf, std::max<size_t>(1, (size_t) S.nsuper) * 8 * sizeof(long long)));
@@ -289,6 +319,28 @@ int run_factor_solve(cs3_handle h, const double *ax_dev, const double *b_dev, do
     return CS3_OK;
 }
 
+// What analyze() checks before it touches a pattern, for the stand-alone entry points: Ap[0] == 0, Ap monotone,
+// 0 <= Ai < n (symmetrized_pattern and the etree walk index arrays of length n by Ai).
+int check_pattern(const char *who, int64_t n, const int32_t *Ap, const int32_t *Ai)
+{
+    if (n < 0 || n >= ((int64_t) 1 << 30) || !Ap) { set_error(std::string(who) + ": bad size or null column pointers"); return CS3_ERR_ARG; }
+    if (Ap[0] != 0) { set_error(std::string(who) + ": Ap[0] != 0"); return CS3_ERR_ARG; }
+    for (int64_t j = 0; j < n; ++j)
+        if (Ap[j + 1] < Ap[j]) { set_error(std::string(who) + ": Ap not monotone"); return CS3_ERR_ARG; }
+    const int64_t nnz = n > 0 ? Ap[n] : 0;
+    if (nnz > 0 && !Ai) { set_error(std::string(who) + ": null row indices"); return CS3_ERR_ARG; }
+    for (int64_t p = 0; p < nnz; ++p)
+        if (Ai[p] < 0 || Ai[p] >= n) { set_error(std::string(who) + ": row index out of range"); return CS3_ERR_ARG; }
+    return CS3_OK;
+}
+
+int check_parent(const char *who, int64_t n, const int32_t *parent)
+{
+    for (int64_t j = 0; j < n; ++j)
+        if (parent[j] < -1 || parent[j] >= n || parent[j] == j) { set_error(std::string(who) + ": parent index out of range"); return CS3_ERR_ARG; }
+    return CS3_OK;
+}
+
 int guard(cs3_handle h)
 {
     if (!h) { set_error("null handle"); return CS3_ERR_ARG; }
@@ -313,6 +365,7 @@ int cs3_device_count(void)
 int cs3_amd(int64_t order, int64_t m, int64_t n, const int32_t *Ap, const int32_t *Ai, int32_t *q)
 {
     if (m != n || n < 0 || !Ap || !q) { set_error("cs3_amd: square pattern required"); return CS3_ERR_ARG; }
+    if (int rc = check_pattern("cs3_amd", n, Ap, Ai)) return rc;
     try {
         if (order == CS3_ORDER_NATURAL) { for (int64_t k = 0; k < n; ++k) q[k] = (int32_t) k; return CS3_OK; }
         if (order != CS3_ORDER_AMD) { set_error("cs3_amd: order must be 0 or 1"); return CS3_ERR_ARG; }
@@ -328,6 +381,7 @@ int cs3_amd(int64_t order, int64_t m, int64_t n, const int32_t *Ap, const int32_
 int cs3_etree(int64_t n, const int32_t *Ap, const int32_t *Ai, int32_t *parent)
 {
     if (n < 0 || !Ap || !parent) { set_error("cs3_etree: null argument"); return CS3_ERR_ARG; }
+    if (int rc = check_pattern("cs3_etree", n, Ap, Ai)) return rc;
     try { etree_upper(n, Ap, Ai, parent); }
     catch (const std::exception &e) { set_error(e.what()); return CS3_ERR_ALLOC; }
     return CS3_OK;
@@ -336,6 +390,7 @@ int cs3_etree(int64_t n, const int32_t *Ap, const int32_t *Ai, int32_t *parent)
 int cs3_post(int64_t n, const int32_t *parent, int32_t *post)
 {
     if (n < 0 || !parent || !post) { set_error("cs3_post: null argument"); return CS3_ERR_ARG; }
+    if (int rc = check_parent("cs3_post", n, parent)) return rc;
     try { tree_postorder(n, parent, post); }
     catch (const std::exception &e) { set_error(e.what()); return CS3_ERR_ALLOC; }
     return CS3_OK;
@@ -345,6 +400,10 @@ int cs3_counts(int64_t n, const int32_t *Ap, const int32_t *Ai, const int32_t *p
                const int32_t *post, int32_t *colcount)
 {
     if (n < 0 || !Ap || !parent || !post || !colcount) { set_error("cs3_counts: null argument"); return CS3_ERR_ARG; }
+    if (int rc = check_pattern("cs3_counts", n, Ap, Ai)) return rc;
+    if (int rc = check_parent("cs3_counts", n, parent)) return rc;
+    for (int64_t k = 0; k < n; ++k)
+        if (post[k] < 0 || post[k] >= n) { set_error("cs3_counts: postorder index out of range"); return CS3_ERR_ARG; }
     try { cholesky_counts(n, Ap, Ai, parent, post, colcount); }
     catch (const std::exception &e) { set_error(e.what()); return CS3_ERR_ALLOC; }
     return CS3_OK;
@@ -375,14 +434,7 @@ int cs3_free(cs3_handle h)
     if (!h) return CS3_OK;
     if (h->on_device) {
         (void) hipDeviceSynchronize();
-        DeviceFactor &D = h->D;
-        if (h->factor_graph) (void) hipGraphExecDestroy(h->factor_graph);
-        drop_solve_graphs(h);
-        if (h->cap_stream) (void) hipStreamDestroy(h->cap_stream);
-        h->fj.destroy();
-        void *ptrs[] = {D.fdesc, D.st_idx, D.asm_src, D.asm_tgt, D.long_src,
-                        D.sdesc, D.fasm_src, D.fasm_tgt, D.flong_src, D.rl_pairs, D.q, D.ax, D.pool, D.dbuf, D.tbuf, D.bigv, D.cv, D.xp, D.status, h->d_lmap, h->d_umap, h->d_lx, h->d_ux};
-        for (void *p : ptrs) if (p) (void) hipFree(p);
+        release_device(h);
     }
     delete h;
     return CS3_OK;
@@ -601,6 +653,8 @@ static int csc_trisolve(int64_t n, const int32_t *Gp, const int32_t *Gi, const d
 {
     if (n < 0 || k < 1 || k > INT_MAX || !Gp || !x) { set_error("triangular solve: bad argument"); return CS3_ERR_ARG; }
     if (n == 0) return CS3_OK;
+    if (int rc = check_pattern("triangular solve", n, Gp, Gi)) return rc;
+    if (!Gx) { set_error("triangular solve: null values"); return CS3_ERR_ARG; }
     TriSchedule T;
     try { tri_schedule(n, Gp, Gi, lower, T); }
     catch (const std::bad_alloc &) { set_error("triangular solve: out of memory"); return CS3_ERR_ALLOC; }

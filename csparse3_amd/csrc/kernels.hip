@@ -2104,10 +2104,11 @@ hipError_t ForkJoin::init()
 
 void ForkJoin::destroy()
 {
-    for (int i = 0; i < NSIDE; ++i) if (side[i]) (void) hipStreamDestroy(side[i]);
-    if (aux) (void) hipStreamDestroy(aux);
+    for (int i = 0; i < NSIDE; ++i) if (side[i]) { (void) hipStreamDestroy(side[i]); side[i] = nullptr; }
+    if (aux) { (void) hipStreamDestroy(aux); aux = nullptr; }
     for (hipEvent_t e : events) (void) hipEventDestroy(e);
     events.clear();
+    next = 0;
 }
 
 hipError_t ForkJoin::event(hipEvent_t *out)

@@ -11,7 +11,8 @@
 // The permutation is not unique: it depends on how ties are broken (LIFO
 // degree lists, lowest non-empty list first) and on the order of the
 // adjacency lists.  This file makes the same choices as oracle/cs_oracle.c so
-// that the two agree index for index; tests/test_ordering.py checks that.
+// that the two agree index for index (tests/test_symbolic.py::test_amd_bit_exact); the permutation is
+// also held to AMD's defining properties without the oracle (tests/test_symbolic.py::test_amd_fill_quality).
 //
 // The elimination is inherently one pivot at a time, so it runs on the host
 // inside the shared library ("AMD on a GPU"); the north-star

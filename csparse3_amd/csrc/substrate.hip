@@ -425,11 +425,13 @@ int cs3_csc_add(int64_t m, int64_t n, const int32_t *Ap, const int32_t *Ai, cons
     return CS3_OK;
 }
 
-// B = A[rows, cols] with the reference's semantics (csc_sub_matrix, csc_numba.py:464-502); Bi / Bx hold at
-// least nnz(A) entries (as the reference allocates), the number used is Bp[ncols].
+// B = A[rows, cols] with the reference's semantics (csc_sub_matrix, csc_numba.py:464-502); Bi / Bx hold b_cap
+// entries (the reference allocates nnz(A)), the number used is Bp[ncols].  With repeated rows or columns the
+// result can outgrow nnz(A): the reference then runs off its arrays, this function fills Bp, writes nothing
+// else and returns CS3_ERR_ARG, so the caller can retry with Bp[ncols] entries.
 int cs3_csc_sub_matrix(int64_t n, const int32_t *Ap, const int32_t *Ai, const double *Ax,
                        const int32_t *rows, int64_t nrows, const int32_t *cols, int64_t ncols,
-                       int32_t *Bp, int32_t *Bi, double *Bx)
+                       int32_t *Bp, int32_t *Bi, double *Bx, int64_t b_cap)
 {
     if (n < 0 || n > INT_MAX || nrows < 0 || ncols < 0 || nrows > INT_MAX || ncols > INT_MAX || !Ap || !Bp ||
         (nrows > 0 && !rows) || (ncols > 0 && !cols)) { set_error("cs3_csc_sub_matrix: bad argument"); return CS3_ERR_ARG; }
@@ -452,6 +454,11 @@ int cs3_csc_sub_matrix(int64_t n, const int32_t *Ap, const int32_t *Ai, const do
     SUB_HIP(hipGetLastError());
     SUB_HIP(hipMemcpy(Bp, bp.p, (size_t) (ncols + 1) * 4, hipMemcpyDeviceToHost));
     const long long nb = Bp[ncols];
+    if (nb > b_cap || (nb > 0 && (!Bi || !Bx))) {
+        set_error("cs3_csc_sub_matrix: result has " + std::to_string(nb) + " entries, room for " + std::to_string(b_cap) +
+                  " (repeated rows / columns?)");
+        return CS3_ERR_ARG;
+    }
     SUB_HIP(bi.alloc((size_t) nb * 4)); SUB_HIP(bx.alloc((size_t) nb * 8));
     hipLaunchKernelGGL(k_sub_matrix, dim3(blocks_for(ncols, 128)), dim3(128), 0, 0, ap.as<int>(), ai.as<int>(), ax.as<double>(),
                        dr.as<int>(), (int) nrows, dc.as<int>(), (int) ncols, bp.as<int>(), bi.as<int>(), bx.as<double>(),

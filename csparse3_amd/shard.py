@@ -74,16 +74,49 @@ class HipBackend:
         self.F.factor_status(self.stream())
         return B
 
+    def factor_solve_resident(self, ax_dev, B, tol=0.0):
+        """The same with the values already in HBM (a torch tensor): nothing crosses PCIe inside the call."""
+        self.F.factor_solve_dev(ax_dev.data_ptr(), B.data_ptr(), B.shape[-1], tol, self.stream())
+        self.F.factor_status(self.stream())
+        return B
+
     def to_device(self, a):
+        if isinstance(a, torch.Tensor):
+            return a.to(self.device, dtype=torch.float64)
         return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).to(self.device)
 
 
-def solve_many_rhs(backend, Ax, B, tol=0.0, group=None, root=0):
+class _Phases:
+    """Wall-clock of the phases of a sharded call: `sync()` (device synchronise + barrier, supplied by the caller)
+    closes a phase, so the times are max-over-ranks comparable.  Without `timings` nothing is synchronised."""
+
+    def __init__(self, timings, sync):
+        self.t, self.sync = timings, sync
+        self.t0 = None
+        if timings is not None and sync is not None:
+            sync()
+            import time
+            self.clock = time.perf_counter
+            self.t0 = self.clock()
+
+    def mark(self, name):
+        if self.t0 is None:
+            return
+        self.sync()
+        now = self.clock()
+        self.t[name] = self.t.get(name, 0.0) + (now - self.t0)
+        self.t0 = now
+
+
+def solve_many_rhs(backend, Ax, B, tol=0.0, group=None, root=0, timings=None, sync=None):
     """Config 4: A X = B with B [n, k] known on `root`; returns X [n, k] on root, None elsewhere.
 
-    Collectives: one broadcast of the factor panels, one gather of the solution slabs.
+    Collectives: one broadcast of the factor panels, one gather of the solution slabs; the RHS slabs leave the
+    root as one batch of point-to-point sends (every xGMI link of the root busy at once).
+    `timings` (dict) receives seconds per phase: factor, broadcast, scatter, solve, gather.
     """
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if world_ready() else (0, 1)
+    ph = _Phases(timings, sync)
     n, k = B.shape if rank == root else (None, None)
     meta = torch.tensor([n or 0, k or 0], dtype=torch.int64)
     if world > 1:
@@ -93,13 +126,16 @@ def solve_many_rhs(backend, Ax, B, tol=0.0, group=None, root=0):
     # ---- factor once, broadcast the panels
     if rank == root:
         backend.factor(Ax, tol)
+        ph.mark("factor")
         fac = backend.export_factor()
     else:
+        ph.mark("factor")
         fac = backend.empty_factor()
     if world > 1:
         dist.broadcast(fac, src=root, group=group)
         if rank != root:
             backend.import_factor(fac)
+    ph.mark("broadcast")
     # ---- scatter the RHS columns as contiguous slabs [n, k_r]
     lo, hi = shard_range(k, world, rank)
     if world > 1:
@@ -112,37 +148,59 @@ def solve_many_rhs(backend, Ax, B, tol=0.0, group=None, root=0):
         _scatter_uneven(mine, slabs, root, group)
     else:
         mine = backend.to_device(B).contiguous()
+    ph.mark("scatter")
     if hi > lo:
         backend.solve(mine)
+    ph.mark("solve")
     # ---- gather the solution slabs
     if world == 1:
+        ph.mark("gather")
         return mine
     out = _gather_uneven(mine, [(n, shard_range(k, world, r)[1] - shard_range(k, world, r)[0])
                                 for r in range(world)], root, group)
-    if rank != root:
-        return None
-    return torch.cat(out, dim=1)
+    X = torch.cat(out, dim=1) if rank == root else None
+    ph.mark("gather")
+    return X
 
 
-def solve_many_matrices(make_backend, AX, B, tol=0.0, group=None, root=0):
-    """Config 5: AX [nmat, nnz] values of matrices sharing one pattern, B [nmat, n, k] right-hand
-    sides, both known on every rank (synthetic inputs are generated from seeds); each rank
-    factorises and solves its slice.  Returns X [nmat, n, k] on root, None elsewhere.
-    `make_backend(batch)` builds a backend for `batch` matrices."""
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    nmat = AX.shape[0]
+def world_ready():
+    return dist.is_available() and dist.is_initialized()
+
+
+def solve_many_matrices(make_backend, AX, B, tol=0.0, group=None, root=0, timings=None, sync=None,
+                        local_values=False, total=None):
+    """Config 5: matrices sharing one pattern, values AX [nmat, nnz], right-hand sides B [nmat, n, k] (known on
+    every rank: synthetic inputs are generated from seeds); each rank factorises and solves its contiguous
+    slice -- no data-path collective -- and the solutions are gathered.  Returns X [nmat, n, k] on root, None
+    elsewhere.  `make_backend(batch)` builds a backend for `batch` matrices.
+    local_values: AX holds only THIS rank's slice (rows lo..hi of the batch of `total` matrices).
+    `timings` (dict) receives seconds per phase: upload, factor_solve, gather."""
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if world_ready() else (0, 1)
+    ph = _Phases(timings, sync)
+    nmat = total if local_values else AX.shape[0]
     lo, hi = shard_range(nmat, world, rank)
     X = None
     be = None
     if hi > lo:
         be = make_backend(hi - lo)
         Bd = be.to_device(B[lo:hi]).contiguous()
-        if hasattr(be, "factor_solve"):
-            X = be.factor_solve(AX[lo:hi], Bd, tol)
+        vals = AX if local_values else AX[lo:hi]
+        if hasattr(be, "to_device") and hasattr(be, "factor_solve_resident"):
+            ax_dev = be.to_device(vals)
+            ph.mark("upload")
+            X = be.factor_solve_resident(ax_dev, Bd, tol)
+        elif hasattr(be, "factor_solve"):
+            ph.mark("upload")
+            X = be.factor_solve(vals, Bd, tol)
         else:
-            be.factor(AX[lo:hi], tol)
+            ph.mark("upload")
+            be.factor(vals, tol)
             X = be.solve(Bd)
+    else:
+        ph.mark("upload")
+    ph.mark("factor_solve")
     if world == 1:
+        ph.mark("gather")
         return X
     shapes = [(shard_range(nmat, world, r)[1] - shard_range(nmat, world, r)[0],) + tuple(B.shape[1:])
               for r in range(world)]
@@ -150,7 +208,9 @@ def solve_many_matrices(make_backend, AX, B, tol=0.0, group=None, root=0):
     if X is None:
         X = torch.empty((0,) + tuple(B.shape[1:]), dtype=torch.float64, device=dev)
     out = _gather_uneven(X, shapes, root, group)
-    return torch.cat(out, dim=0) if rank == root else None
+    res = torch.cat(out, dim=0) if rank == root else None
+    ph.mark("gather")
+    return res
 
 
 def _comm_device(backend):
@@ -159,25 +219,28 @@ def _comm_device(backend):
 
 
 def _scatter_uneven(recv, slabs, root, group):
-    """Point-to-point fan-out from root (slabs differ in width, so no scatter collective)."""
+    """Fan-out from root as ONE batch of point-to-point sends (slabs may differ in width, so no scatter collective;
+    batched, RCCL drives all of the root's xGMI links at once instead of one peer after the other)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ops = []
     if rank == root:
-        reqs = []
         for r in range(world):
             if r == root:
                 recv.copy_(slabs[r])
             elif slabs[r].numel() > 0:
-                reqs.append(dist.isend(slabs[r], dst=r, group=group))
-        for q in reqs:
-            q.wait()
+                ops.append(dist.P2POp(dist.isend, slabs[r], r, group))
     elif recv.numel() > 0:
-        dist.recv(recv, src=root, group=group)
+        ops.append(dist.P2POp(dist.irecv, recv, root, group))
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
 
 
 def _gather_uneven(send, shapes, root, group):
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ops, out = [], None
     if rank == root:
-        out, reqs = [], []
+        out = []
         for r in range(world):
             if r == root:
                 out.append(send)
@@ -185,10 +248,10 @@ def _gather_uneven(send, shapes, root, group):
             t = torch.empty(shapes[r], dtype=send.dtype, device=send.device)
             out.append(t)
             if t.numel() > 0:
-                reqs.append(dist.irecv(t, src=r, group=group))
-        for q in reqs:
+                ops.append(dist.P2POp(dist.irecv, t, r, group))
+    elif send.numel() > 0:
+        ops.append(dist.P2POp(dist.isend, send, root, group))
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
             q.wait()
-        return out
-    if send.numel() > 0:
-        dist.send(send, dst=root, group=group)
-    return None
+    return out

@@ -153,6 +153,15 @@ def jacobian_like(nbus=118, nedges=186, n_pv=34, seed=118):
     return _coo_to_sorted_csc(n, rows.astype(np.int64), cols.astype(np.int64), vals)
 
 
+def jacobian_config2(seed=118):
+    """BASELINE.json configs[1] at the size it states (~400 x 400, ~3k nnz): the same Jacobian builder on a
+    220-bus / 340-branch network with 38 PV buses (2 * 219 - 38 = 400 unknowns, 2 986 entries).  The true
+    IEEE-118 case is not available offline and would give a 181 x 181 Jacobian (117 + 64 unknowns), so the
+    config's own size figures are used; `jacobian_like()` stays as the 118-bus-sized case.
+    -> (m, n, Ap, Ai, Ax)"""
+    return jacobian_like(nbus=220, nedges=340, n_pv=38, seed=seed)
+
+
 def grid_graph_edges(n, offsets, chord_frac, rng):
     """1-D chain with extra local ties i <-> i+k for k in offsets, plus
     chord_frac * n random long chords."""

@@ -198,10 +198,12 @@ int cs3_csc_add(int64_t m, int64_t n, const int32_t *Ap, const int32_t *Ai, cons
                 const int32_t *Bp, const int32_t *Bi, const double *Bx, double alpha, double beta,
                 int32_t *Cp, int32_t *Ci, double *Cx);
 /* B = A[rows, cols] exactly as csc_sub_matrix computes it (csc_numba.py:464-502), its running row counter
- * included.  Bp[ncols + 1]; Bi / Bx: room for nnz(A); used: Bp[ncols]. */
+ * included.  Bp[ncols + 1]; Bi / Bx: room for b_cap entries (the reference allocates nnz(A)); used: Bp[ncols].
+ * Repeated rows / columns can need more than nnz(A): then Bp is filled, nothing else is written and the call
+ * returns CS3_ERR_ARG (the reference runs off its arrays there). */
 int cs3_csc_sub_matrix(int64_t n, const int32_t *Ap, const int32_t *Ai, const double *Ax,
                        const int32_t *rows, int64_t nrows, const int32_t *cols, int64_t ncols,
-                       int32_t *Bp, int32_t *Bi, double *Bx);
+                       int32_t *Bp, int32_t *Bi, double *Bx, int64_t b_cap);
 /* label[i] = smallest node of the island (connected component of the pattern, either direction) that holds
  * node i: find_islands (csc_numba.py:744-808) lists islands by ascending smallest node, CscMat.islands
  * (csc.py:515-521) sorts each -- both follow from the labels. */

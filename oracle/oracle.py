@@ -43,13 +43,35 @@ def build(force=False):
 
 
 _lib = None
+_native = False
+
+
+def use_native():
+    """Switch this module to oracle/_native/liboracle_native.so (-O3 -march=native, built on the spot by
+    `make native`): the CPU-BASELINE build for bench.py, compiled on the host it is timed on.  Returns the
+    compiler flags used, or None when the build failed and the portable library stays in use."""
+    global _lib, _native
+    path = os.path.join(_HERE, "_native", "liboracle_native.so")
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _lib = None
+        _native = True
+        lib()
+        return "gcc -O3 -march=native"
+    except Exception:
+        _native = False
+        _lib = None
+        return None
 
 
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(_LIB_PATH)
+        if _native:
+            _lib = C.CDLL(os.path.join(_HERE, "_native", "liboracle_native.so"))
+        else:
+            build()
+            _lib = C.CDLL(_LIB_PATH)
         _lib.orc_add.restype = _CscP
         _lib.orc_transpose.restype = _CscP
         _lib.orc_coo_to_csc.restype = _CscP

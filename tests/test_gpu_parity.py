@@ -19,6 +19,7 @@ def _cases():
     m, n, Ap, Ai, Ax, b, xt = synth.toy10()
     yield "toy10", (m, n, Ap, Ai, Ax)
     yield "jacobian118", synth.jacobian_like()
+    yield "config2", synth.jacobian_config2()                                   # BASELINE configs[1] at its stated size
     yield "grid2k", synth.grid_jacobian(n=2000, seed=7)
     yield "grid20k", synth.grid_jacobian(n=20000, seed=11)
     yield "denseblock300", synth.dense_block_matrix(n=700, nd=300, seed=1)      # fronts beyond the LDS
@@ -252,6 +253,71 @@ def test_config3_full_size_properties(gpu):
         assert np.abs(A @ x - b).max() <= 1e-13 * (scale * np.abs(x).max() + np.abs(b).max())
     assert rel_err(x12, 2.0 * x1 - 3.0 * x2) <= 1e-12
     assert rel_err(X[:, 0], x1) <= 1e-13 and rel_err(X[:, 1], x2) <= 1e-13
+
+
+def test_config4_slice_full_size_properties(gpu, orc):
+    """BASELINE configs[3] on one GPU at its per-GPU size: the 50k matrix, factor once, 128 right-hand sides
+    (1024 over 8 GPUs).  Residual of every column, agreement of a column with the single-RHS path, oracle parity
+    of three columns, bitwise run-to-run reproducibility."""
+    m, n, Ap, Ai, Ax = synth.grid_jacobian()
+    A = csc_to_scipy(m, n, Ap, Ai, Ax)
+    B = synth.grid_rhs(n, 128, seed=1024)
+    with gpu.Factorization(m, n, Ap, Ai) as F:
+        F.factor(Ax, 1e-3)
+        X = F.solve(B)
+        X2 = F.solve(B)
+        x5 = F.solve(np.ascontiguousarray(B[:, 5]))
+        Lp, Li, Lx, Up, Ui, Ux = F.factors()
+        o = F.ordering()
+    assert np.array_equal(X, X2)                                            # no float atomics anywhere
+    scale = abs(A).sum(axis=0).max()
+    R = A @ X - B
+    assert np.abs(R).max() <= 1e-13 * (scale * np.abs(X).max() + np.abs(B).max())
+    assert rel_err(X[:, 5], x5) <= 1e-12
+    for j in (0, 77, 127):
+        w = np.empty(n); w[o["pinv"]] = B[:, j]
+        orc.csc_lsolve_f(n, Lp, Li, Lx, w)
+        orc.csc_usolve_f(n, Up, Ui, Ux, w)
+        want = np.empty(n); want[o["q"]] = w
+        assert rel_err(X[:, j], want) <= RTOL
+
+
+def test_config5_slice_full_size_properties(gpu, orc):
+    """BASELINE configs[4] on one GPU at its per-GPU size: 64 SPD 5k x 5k matrices sharing a pattern (512 over
+    8 GPUs), Cholesky factor + one solve each through the fused call.  Residual of every matrix, one matrix
+    against the oracle (pattern bit-exact, values 1e-10), bitwise equality with the unbatched handle."""
+    import torch
+    n5, nmat = 5000, 64
+    ei, ej = synth.spd_grid_pattern(n5, seed=5000)
+    mats = [synth.spd_grid_matrix(n5, ei, ej, seed=5000 + i) for i in range(nmat)]
+    m, n, Ap, Ai, _ = mats[0]
+    AX = np.stack([mm[4] for mm in mats])
+    B = np.random.default_rng(0).standard_normal((nmat, n, 1))
+    dev = torch.device("cuda", 0)
+    sh = torch.cuda.current_stream().cuda_stream
+    with gpu.Factorization(m, n, Ap, Ai, kind=gpu.CS3_CHOLESKY, batch=nmat) as F:
+        d_ax = torch.from_numpy(AX).to(dev)
+        d_x = torch.from_numpy(B.copy()).to(dev)
+        F.factor_solve_dev(d_ax.data_ptr(), d_x.data_ptr(), 1, 0.0, sh)
+        F.factor_status(sh)
+        X = d_x.cpu().numpy()
+        d_x2 = torch.from_numpy(B.copy()).to(dev)
+        F.factor_dev(d_ax.data_ptr(), 0.0, sh)
+        F.solve_dev(d_x2.data_ptr(), 1, sh)
+        F.factor_status(sh)
+        assert torch.equal(d_x, d_x2)                                       # fused == factor, then solve
+        q = F.ordering()["q"]
+        fac = {i: F.factors(b=i) for i in (0, 37, 63)}
+    for i in range(nmat):
+        A = csc_to_scipy(m, n, Ap, Ai, AX[i])
+        r = np.abs(A @ X[i, :, 0] - B[i, :, 0]).max()
+        assert r <= 1e-12 * (abs(A).sum(axis=0).max() * np.abs(X[i]).max() + np.abs(B[i]).max()), (i, r)
+    for i, (Lp, Li, Lx, _, _, _) in fac.items():
+        assert_factor_equal(n, (Lp, Li, Lx), _oracle_chol(orc, n, Ap, Ai, AX[i], q), "config-5 matrix %d" % i)
+    with gpu.Factorization(m, n, Ap, Ai, kind=gpu.CS3_CHOLESKY) as G:      # the same matrix alone: same values to 1e-13
+        G.factor(AX[37])
+        x1 = G.solve(B[37])
+    assert rel_err(X[37], x1) <= 1e-12
 
 
 # ------------------------------------------------------------- edge cases ----

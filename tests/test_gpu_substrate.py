@@ -59,6 +59,20 @@ def test_sub_matrix_matches_golden(gpu, tag):
     assert _same((Bp, Bi, Bx), (GOLD[tag + "_p"], GOLD[tag + "_i"], GOLD[tag + "_x"]))
 
 
+def test_sub_matrix_with_repeated_rows_is_refused_not_overrun(gpu):
+    """Repeated rows / columns make the result larger than nnz(A), which is all the reference allocates
+    (csc_numba.py:476-478: it would index past its arrays).  The library reports it instead of writing."""
+    Ap, Ai, Ax = GOLD["r1_Ap"], GOLD["r1_Ai"], GOLD["r1_Ax"]
+    rows = np.tile(np.arange(40, dtype=np.int32), 3)
+    cols = np.tile(np.arange(40, dtype=np.int32), 2)
+    with pytest.raises(gpu.Cs3Error) as e:
+        gpu.csc_sub_matrix(40, int(Ap[40]), Ap, Ai, Ax, rows, cols)
+    assert "room for" in str(e.value)
+    # once each, the same call is fine and returns A itself with the reference's row numbering
+    nz, Bp, Bi, Bx = gpu.csc_sub_matrix(40, int(Ap[40]), Ap, Ai, Ax, rows[:40], cols[:40])
+    assert nz == int(Ap[40])
+
+
 def test_find_islands_matches_golden(gpu):
     isl = gpu.find_islands(30, GOLD["isl_Ap"], GOLD["isl_Ai"])
     assert len(isl) == int(GOLD["isl_count"]) and [len(x) for x in isl] == list(GOLD["isl_sizes"])

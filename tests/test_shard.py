@@ -70,7 +70,10 @@ def _worker(rank, world, port, mode, out):
             B = np.random.default_rng(0).standard_normal((n, 7))          # 7 columns over 2 ranks: 4 + 3
             be = OracleBackend(m, n, Ap, Ai)
             be._probe_values = Ax
-            X = shard.solve_many_rhs(be, Ax if rank == 0 else None, B if rank == 0 else None, tol=1e-3)
+            tm = {}
+            X = shard.solve_many_rhs(be, Ax if rank == 0 else None, B if rank == 0 else None, tol=1e-3,
+                                     timings=tm, sync=dist.barrier)
+            assert set(tm) == {"factor", "broadcast", "scatter", "solve", "gather"} and all(v >= 0.0 for v in tm.values())
             if rank == 0:
                 np.save(out, X.numpy())
         else:
@@ -80,8 +83,15 @@ def _worker(rank, world, port, mode, out):
             m, n, Ap, Ai, _ = mats[0]
             AX = np.stack([mm[4] for mm in mats])
             B = np.random.default_rng(1).standard_normal((5, n, 2))
-            X = shard.solve_many_matrices(lambda b: OracleBackend(m, n, Ap, Ai, batch=b), AX, B, tol=1e-3)
+            X = shard.solve_many_matrices(lambda b: OracleBackend(m, n, Ap, Ai, batch=b), AX, B.copy(), tol=1e-3)   # (the CPU stand-in solves in place)
+            # every rank holding only its own slice of the values gives the same result
+            lo, hi = shard.shard_range(5, world, rank)
+            tm = {}
+            X2 = shard.solve_many_matrices(lambda b: OracleBackend(m, n, Ap, Ai, batch=b), AX[lo:hi], B.copy(), tol=1e-3,
+                                           local_values=True, total=5, timings=tm, sync=dist.barrier)
+            assert set(tm) == {"upload", "factor_solve", "gather"}
             if rank == 0:
+                assert torch.equal(X, X2)
                 np.save(out, X.numpy())
     finally:
         dist.destroy_process_group()
@@ -131,6 +141,8 @@ def test_factor_export_import_roundtrip_on_the_gpu(gpu):
     be1 = shard.HipBackend(m, n, Ap, Ai)
     be0.factor(Ax, 1e-3)
     be1.import_factor(be0.export_factor().clone())
+    be1.F.factor_status(be1.stream())          # an importing handle never ran a prologue: its status word must read clean
+    assert be1.F.info.fail_col == -1
     x0 = be0.solve(be0.to_device(b)).cpu().numpy()
     x1 = be1.solve(be1.to_device(b)).cpu().numpy()
     assert np.array_equal(x0, x1)

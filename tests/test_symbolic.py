@@ -1,5 +1,9 @@
 """Host side of the HIP library (no GPU needed): ordering and symbolic analysis
-against the oracle, bit-exact; the C ABI exports every symbol the header declares."""
+against the oracle, bit-exact; the C ABI exports every symbol the header declares.
+
+Every test here runs TWICE: unmarked in the CPU suite (`-m "not gpu"`) and with the `gpu` marker in the
+driver's GPU run (`-m gpu`), so that the AMD / etree / postorder / column-count / pattern parity is part of
+the recorded GPU evidence as well (the code under test is the same host C++ either way)."""
 import ctypes as C
 import os
 import re
@@ -13,10 +17,16 @@ from helpers import symmetrized
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.fixture(autouse=True, params=[pytest.param("cpu-suite"), pytest.param("gpu-suite", marks=pytest.mark.gpu)])
+def suite(request):
+    return request.param
+
+
 def _cases():
     m, n, Ap, Ai, Ax, b, xt = synth.toy10()
     yield "toy10", (m, n, Ap, Ai, Ax)
     yield "jacobian118", synth.jacobian_like()
+    yield "config2", synth.jacobian_config2()
     yield "grid3k", synth.grid_jacobian(n=3000, seed=5)
     yield "grid50k", synth.grid_jacobian()
     yield "denseblock", synth.dense_block_matrix(n=400, nd=150, seed=2)
@@ -129,6 +139,69 @@ def test_bad_input_is_rejected(hip):
         hip.Factorization(m, n, Ap, dup)                                     # duplicate entry
     with pytest.raises(AssertionError):
         hip.Factorization(m, n + 1, Ap, Ai)                                  # not square
+
+
+def test_stand_alone_symbolic_entry_points_validate_their_pattern(hip):
+    """cs3_amd / cs3_etree / cs3_counts index arrays of length n by Ai: bad patterns must come back as errors."""
+    m, n, Ap, Ai, Ax = CASES["toy10"]
+    bad_row = Ai.copy(); bad_row[2] = n + 3
+    bad_ptr = Ap.copy(); bad_ptr[3] = bad_ptr[2] - 1
+    for ap, ai in ((Ap, bad_row), (bad_ptr, Ai)):
+        with pytest.raises(hip.Cs3Error):
+            hip.csc_amd_f(1, m, n, ap, ai)
+        with pytest.raises(hip.Cs3Error):
+            hip.csc_etree_f(n, ap, ai)
+    parent = hip.csc_etree_f(n, Ap, Ai)
+    bad_parent = parent.copy(); bad_parent[0] = n + 1
+    with pytest.raises(hip.Cs3Error):
+        hip.csc_post_f(n, bad_parent)
+    with pytest.raises(hip.Cs3Error):
+        hip.csc_counts_f(n, Ap, Ai, bad_parent, np.arange(n, dtype=np.int32))
+    # null row indices with a non-empty pattern
+    assert hip.lib().cs3_amd(1, n, n, Ap.ctypes.data_as(C.POINTER(C.c_int32)), None,
+                             np.empty(n, np.int32).ctypes.data_as(C.POINTER(C.c_int32))) == -1
+
+
+def test_amd_fill_quality(hip):
+    """Oracle-independent check of the ordering: a permutation whose fill is in the range of SciPy's SuperLU
+    minimum-degree orderings on the same pattern (AMD is not unique, so there is no bit-exact external answer;
+    SURVEY.md section 8c.3)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    m, n, Ap, Ai, Ax = CASES["grid3k"]
+    q = hip.csc_amd_f(1, m, n, Ap, Ai)
+    assert sorted(q.tolist()) == list(range(n))
+    with hip.Factorization(m, n, Ap, Ai) as F:
+        nnz_l = int(F.info.nnz_l)
+    A = sp.csc_matrix((Ax, Ai, Ap), shape=(n, n))
+    lu = spl.splu(A, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+    assert nnz_l <= 1.15 * lu.L.nnz, "AMD fill %d vs SuperLU MMD_AT_PLUS_A %d" % (nnz_l, lu.L.nnz)
+    with hip.Factorization(m, n, Ap, Ai, order=hip.ORDER_NATURAL) as F:
+        assert nnz_l < int(F.info.nnz_l)                  # and it beats no ordering at all
+
+
+def test_cscmat_reanalyses_when_the_pattern_changes(hip):
+    """CscMat caches its symbolic analysis; the cache key includes a digest of indptr / indices, so changing
+    the pattern in place (or reassigning the arrays) between two factorisations cannot reuse a stale one."""
+    from csparse3_amd.csc import CscMat
+    m, n, Ap, Ai, Ax = CASES["jacobian118"]
+    A = CscMat(m, n, indptr=Ap.copy(), indices=Ai.copy(), data=Ax.copy())
+    F1 = A._analysis(hip.CS3_LU, hip.ORDER_AMD, None)
+    assert A._analysis(hip.CS3_LU, hip.ORDER_AMD, None) is F1            # unchanged pattern: cached
+    A.data[:] *= 2.0
+    assert A._analysis(hip.CS3_LU, hip.ORDER_AMD, None) is F1            # values do not matter
+    nnz1 = int(F1.info.nnz_a)
+    m2, n2, Ap2, Ai2, Ax2 = synth.jacobian_like(seed=7)                  # same size, another pattern
+    assert n2 == n
+    A.indptr, A.indices, A.data = Ap2, Ai2, Ax2
+    F2 = A._analysis(hip.CS3_LU, hip.ORDER_AMD, None)
+    assert F2 is not F1 and int(F2.info.nnz_a) == int(Ap2[n]) and (nnz1 != int(Ap2[n]) or not np.array_equal(Ai, Ai2))
+    col = int(np.argmax(np.diff(A.indptr) >= 3))
+    p = A.indptr[col]
+    free = np.setdiff1d(np.arange(n), A.indices[A.indptr[col]:A.indptr[col + 1]])
+    A.indices[p if A.indices[p] != col else p + 1] = free[0]            # in-place edit of one row index
+    F3 = A._analysis(hip.CS3_LU, hip.ORDER_AMD, None)
+    assert F3 is not F2
 
 
 def test_numeric_entry_points_fail_loudly_without_a_gpu(hip):

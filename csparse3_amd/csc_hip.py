@@ -12,7 +12,9 @@ There is no CPU fallback: if the shared library is missing or no GPU is
 visible the numeric entry points raise.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -52,10 +54,38 @@ class NotPositiveDefinite(Cs3Error, ArithmeticError):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so / libhsa-runtime64.so; the
+    stream handles and device pointers that callers hand to this library (torch.cuda.current_stream(),
+    Tensor.data_ptr()) only mean something to the runtime that made them, and a second runtime copy in the
+    process does not even see the GPU once the first has opened it (measured on the GPU box: loading this
+    library first and importing torch afterwards leaves torch with "No HIP GPUs are available").  So when
+    torch is installed but not imported yet, its runtime is loaded here, globally, before our library: the
+    loader then binds our libamdhip64.so.7 dependency to that copy, and a later `import torch` finds it too.
+    Without torch the system ROCm runtime is used.  CS3_SYSTEM_HIP=1 skips this."""
+    if "torch" in sys.modules or os.environ.get("CS3_SYSTEM_HIP") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def lib():
     """Load the shared library; fail loudly when it has not been built."""
     global _lib
     if _lib is None:
+        _share_torch_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

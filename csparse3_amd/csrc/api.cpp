@@ -110,6 +110,9 @@ int ensure_device_impl(cs3_handle h)
     D.kind = S.kind; D.n = S.n; D.nnz_a = S.nnzA; D.batch = h->batch;
     D.vals_size = S.vals_size; D.pool_size = S.pool_size; D.cv_size = S.cv_size; D.big_begin = S.big_begin;
     D.bv_size = S.bv_size;
+    D.zero_big = false;
+    for (const LaunchGroup &g : S.groups)
+        if (g.cls == FC_BIG && !big_group_in_one_workgroup(S.kind, h->batch, g)) D.zero_big = true;
     std::vector<FrontDesc> fdesc(S.nsuper);
     i64 dbuf_size = 0;
     for (i32 t = 0; t < S.nsuper; ++t) {

@@ -42,6 +42,7 @@ struct DeviceFactor {
     long long n = 0, nnz_a = 0, batch = 1;
     long long vals_size = 0, pool_size = 0, cv_size = 0;
     long long big_begin = 0;      // big-front buffers: pool[big_begin, vals_size), zeroed per factorisation
+    bool zero_big = true;         //   ... by the prologue, unless every big front runs in k_front_wg (which zeroes its own)
     FrontDesc *fdesc = nullptr;
     int *st_idx = nullptr;        // row structures (backward sweep: rows of the ancestors)
     int *asm_src = nullptr, *asm_tgt = nullptr, *long_src = nullptr;
@@ -77,6 +78,7 @@ struct ForkJoin {
 };
 
 hipError_t prepare_kernels();
+bool big_group_in_one_workgroup(int kind, long long batch, const LaunchGroup &g);
 hipError_t launch_factor_levels(const DeviceFactor &D, const std::vector<LaunchGroup> &groups,
                                 double inv_tol, hipStream_t st, ForkJoin &fj);
 hipError_t launch_solve_levels(const DeviceFactor &D, const std::vector<LaunchGroup> &groups,

@@ -722,6 +722,165 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
 #undef CS3_STAMP
 }
 
+// ------------------------------------ big front, ONE workgroup, ONE launch (batches) --
+// A batch of matrices keeps every CU busy on its own: the front of one matrix then needs no help from other
+// workgroups, and the launch per block step that k_big_step pays for a single matrix (each step waits for the
+// whole grid of the one before) only costs time.  Here one workgroup of 8 waves factorises one front of one
+// matrix from start to end: zero + gather into the dense r x r buffer in HBM (it stays in this CU's L1 / the
+// XCD's L2), then per block of 32 pivots
+//   1. the 32 x 32 diagonal block goes to LDS; every wave eliminates it with 32 rows of the block column (LU:
+//      or 32 columns of the block row) stacked underneath (eliminate_block: the stacked lanes come out as the
+//      solved panel rows), writes them home and into the LDS panels Lp / Up;
+//   2. the trailing matrix gets  F22 -= L21 U12  in 16 x 16 tiles by v_mfma_f64_16x16x4, accumulators loaded
+//      from and stored to the buffer, both operands read from the LDS panels.
+// Two block barriers per 32 pivots, no grid-wide dependency.  Used when the batch alone fills the chip and the
+// panels fit the LDS (launch_front_group decides); results equal k_big_step's to rounding, not bit for bit
+// (the MFMA sums 32 products per step either way, but the diagonal block is updated tile-wise here).
+template <int KIND>
+__global__ void __launch_bounds__(512)
+k_front_wg(const FrontDesc *__restrict__ fdesc, int first,
+           const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
+           const double *__restrict__ ax_all, double *__restrict__ pool_all,
+           long long nnz_a, long long pool_stride, double inv_tol, int *status, int pld, long long *tbuf)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    // diagnostics (CS3_PROFILE=1), matrix 0 of the batch: slot 0 zeroed, 1 gathered, 2 sum of the panel phases,
+    // 3 sum of the update phases, 4 block steps, 5 end -- shader-clock cycles
+    const bool prof = tbuf && blockIdx.y == 0 && threadIdx.x == 0;
+    const long long t_start = prof ? (long long) __builtin_amdgcn_s_memtime() : 0;
+    long long t_panel = 0, t_update = 0, t_mark = 0;
+#define CS3_WSTAMP(p) do { if (prof) tbuf[(long long) (first + blockIdx.x) * 8 + (p)] = (long long) __builtin_amdgcn_s_memtime() - t_start; } while (0)
+    const FrontDesc d = fdesc[first + blockIdx.x];
+    const double *ax = ax_all + (long long) blockIdx.y * nnz_a;
+    double *pool = pool_all + (long long) blockIdx.y * pool_stride;
+    const int r = d.r, w = d.w;
+    double *F = pool + d.lpan;
+    const long long ld = r;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, li = lane & 31;
+    const bool stacked = lane >= 32;
+    double *Dl = sm;                           // Dl[j * 33 + i] = D(i, j)
+    double *Lp = sm + BIG_NB * 33;             // Lp[k * pld + i] = L(ke + i, kb + k)
+    double *Up = Lp + BIG_NB * pld;            // Up[k * pld + j] = U(kb + k, ke + j)   (LU only)
+
+    // ---- assemble: zero the buffer, then F = sum of sources (A entries, children's contribution blocks)
+    for (long long e = tid; e < (long long) r * r; e += 512) F[e] = 0.0;
+    __syncthreads();
+    CS3_WSTAMP(0);
+    gather_front(d.asm_begin, d.asm_count >> 6, wv * GATHER_UNROLL, 8 * GATHER_UNROLL, asm_src, asm_tgt, long_src,
+                 [&](int q) -> const double * { return (q >= 0) ? pool + q : ax + ~q; },
+                 [&](int t, double v) { pool[t] = v; });
+    __syncthreads();
+    CS3_WSTAMP(1);
+
+    bool bad = false;
+    int bad_col = 0;
+    for (int kb = 0; kb < w; kb += BIG_NB) {
+        const int bw = min(BIG_NB, w - kb), ke = kb + bw, nrem = r - ke;
+        if (prof) t_mark = (long long) __builtin_amdgcn_s_memtime();
+        for (int e = tid; e < BIG_NB * BIG_NB; e += 512) {
+            const int i = e & 31, j = e >> 5;
+            Dl[j * 33 + i] = load_if(F, (kb + i) + (long long) (kb + j) * ld, i < bw && j < bw);
+        }
+        __syncthreads();
+        // ---- 1. panels: task 0 = the owner (keeps D) with the first 32 rows of the block column stacked; tasks
+        // 1 .. ng - 1 the other row groups; LU: tasks ng .. 2 ng - 1 the column groups of the block row under D'
+        const int ng = max(1, (nrem + 31) / 32);
+        const int ntask = (KIND == CS3_LU) ? 2 * ng : ng;
+        for (int t = wv; t < ntask; t += 8) {
+            const bool row_wave = t >= ng;
+            const int grp = row_wave ? t - ng : t, s0 = ke + 32 * grp, si = s0 + li;
+            const bool owner = t == 0;
+            double e[BIG_NB];
+            if (!stacked) {
+#pragma unroll
+                for (int j = 0; j < BIG_NB; ++j) {
+                    const double v = row_wave ? Dl[li * 33 + j] : Dl[j * 33 + li];
+                    e[j] = (li < bw && j < bw) ? v : ((li == j) ? 1.0 : 0.0);
+                }
+            } else {
+                const bool mine = si < r;
+                const long long base = row_wave ? (long long) kb + (long long) si * ld : (long long) si + (long long) kb * ld;
+                const long long stride = row_wave ? 1 : ld;
+#pragma unroll
+                for (int j = 0; j < BIG_NB; ++j) e[j] = load_if(F, base + j * stride, mine && j < bw);
+            }
+            eliminate_block<KIND, BIG_NB>(e, row_wave);
+#pragma unroll
+            for (int j = 0; j < BIG_NB; ++j) {
+                if (j < bw) {
+                    const double v = e[j], av = fabs(v);
+                    if (!stacked) {
+                        if (owner && li < bw) {
+                            bool rej;
+                            if (KIND == CS3_LU) {
+                                const double lim = (li == j) ? 1.0e300 : inv_tol;
+                                rej = ((li >= j) & !(av <= lim)) | ((li == j) & !(av > 0.0));
+                            } else {
+                                rej = (li == j) & !(v > 0.0);
+                            }
+                            if (rej && !bad) { bad = true; bad_col = kb + j; }
+                            F[(kb + li) + (long long) (kb + j) * ld] = v;
+                        }
+                    } else if (si < r) {
+                        if (!row_wave) {
+                            if (KIND == CS3_LU && !(av <= inv_tol) && !bad) { bad = true; bad_col = kb + j; }
+                            F[si + (long long) (kb + j) * ld] = v;
+                            Lp[j * pld + (si - ke)] = v;
+                        } else {
+                            F[(kb + j) + (long long) si * ld] = v;
+                            Up[j * pld + (si - ke)] = v;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (prof) { const long long now = (long long) __builtin_amdgcn_s_memtime(); t_panel += now - t_mark; t_mark = now; }
+        // ---- 2. trailing update by MFMA: 16 x 16 tiles of F22 dealt to the 8 waves, operands from the LDS panels
+        if (nrem > 0) {
+            const int nt = (nrem + 15) / 16, mi = lane & 15, mq = lane >> 4;
+            const double *Ua = (KIND == CS3_LU) ? Up : Lp;
+            for (int t = wv; t < nt * nt; t += 8) {
+                const int ti = t % nt, tj = t / nt;             // tile rows ke + 16 ti.., columns ke + 16 tj..
+                if (KIND == CS3_CHOLESKY && ti < tj) continue;
+                const int ia = 16 * ti + mi, ca = 16 * tj + mi; // panel-local row (B operand / output lanes) and column (A operand)
+                const int i = ke + ia;
+                double4_t acc;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int c = ke + 16 * tj + mq + 4 * v;
+                    acc[v] = load_if(F, i + (long long) c * ld, i < r && c < r);
+                }
+#pragma unroll
+                for (int k0 = 0; k0 < BIG_NB; k0 += 4) {
+                    if (k0 < bw) {
+                        const int k = k0 + mq;
+                        const bool kin = k < bw;
+                        const double au = (kin && ca < nrem) ? Ua[k * pld + ca] : 0.0;
+                        const double bl = (kin && ia < nrem) ? -Lp[k * pld + ia] : 0.0;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(au, bl, acc, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int c = ke + 16 * tj + mq + 4 * v;
+                    if (i < r && c < r) F[i + (long long) c * ld] = acc[v];
+                }
+            }
+        }
+        __syncthreads();
+        if (prof) t_update += (long long) __builtin_amdgcn_s_memtime() - t_mark;
+    }
+    if (bad) flag_column(status, d.c0 + bad_col);
+    if (prof) {
+        tbuf[(long long) (first + blockIdx.x) * 8 + 2] = t_panel;
+        tbuf[(long long) (first + blockIdx.x) * 8 + 3] = t_update;
+        tbuf[(long long) (first + blockIdx.x) * 8 + 4] = (w + BIG_NB - 1) / BIG_NB;
+    }
+    CS3_WSTAMP(5);
+#undef CS3_WSTAMP
+}
+
 // Blocked right-looking LU / Cholesky with ONE launch per block step.
 // Launch kb does, tile by tile over the trailing matrix F[kb:, kb:]:
 //   * every tile applies the update of the PREVIOUS panel  C -= L[:, kp:kb] U[kp:kb, :]
@@ -2041,10 +2200,29 @@ static hipError_t launch_big_block(const DeviceFactor &D, const LaunchGroup &g, 
     return hipSuccess;
 }
 
+// One workgroup per (big front, matrix) when the batch fills the chip by itself and the panels fit the LDS.
+static int wg_panel_ld(const LaunchGroup &g) { return (g.max_r + 1) | 1; }
+static size_t wg_lds_bytes(int kind, const LaunchGroup &g)
+{
+    return ((size_t) BIG_NB * 33 + (size_t) (kind == CS3_LU ? 2 : 1) * BIG_NB * wg_panel_ld(g)) * sizeof(double);
+}
+bool big_group_in_one_workgroup(int kind, long long batch, const LaunchGroup &g)
+{
+    static const long long min_batch = getenv("CS3_WG_MIN_BATCH") ? atoll(getenv("CS3_WG_MIN_BATCH")) : 16;
+    return g.cls == FC_BIG && batch >= min_batch && wg_lds_bytes(kind, g) <= 150 * 1024;
+}
+
 template <int KIND>
 static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g, double inv_tol, hipStream_t st)
 {
     const unsigned batch = (unsigned) D.batch;
+    if (big_group_in_one_workgroup(KIND, D.batch, g)) {
+        hipLaunchKernelGGL((k_front_wg<KIND>), dim3((unsigned) g.count, batch), dim3(512), wg_lds_bytes(KIND, g), st, D.fdesc,
+                           g.first, D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool, D.nnz_a, D.pool_size, inv_tol, D.status,
+                           wg_panel_ld(g), D.tbuf);
+        CS3_LAUNCH_CHECK();
+        return hipSuccess;
+    }
     if (g.cls == FC_BIG) {
         hipError_t e = launch_big_gather(D, g, st);
         // one launch per block of BIG_NB pivots, plus the closing launch (last update + last parked block)
@@ -2077,7 +2255,8 @@ hipError_t prepare_kernels()
     const int big = 160 * 1024;
     hipError_t e;
     const void *block_fns[] = {(const void *) k_front_block<CS3_LU, 16>, (const void *) k_front_block<CS3_LU, 32>,
-                               (const void *) k_front_block<CS3_CHOLESKY, 16>, (const void *) k_front_block<CS3_CHOLESKY, 32>};
+                               (const void *) k_front_block<CS3_CHOLESKY, 16>, (const void *) k_front_block<CS3_CHOLESKY, 32>,
+                               (const void *) k_front_wg<CS3_LU>, (const void *) k_front_wg<CS3_CHOLESKY>};
     for (const void *f : block_fns) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, big);
         if (e != hipSuccess) return e;
@@ -2499,7 +2678,7 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
 
 hipError_t launch_prologue(const DeviceFactor &D, const double *ax_src, const double *x_src, int nrhs, hipStream_t st)
 {
-    const long long nzero = D.vals_size - D.big_begin;
+    const long long nzero = D.zero_big ? D.vals_size - D.big_begin : 0;     // k_front_wg zeroes its own buffer
     const long long nax = (ax_src && ax_src != D.ax) ? D.batch * D.nnz_a : 0;
     const long long total = nzero * D.batch + nax + (x_src ? D.n * (long long) nrhs * D.batch : 0);
     hipLaunchKernelGGL(k_prologue, dim3(grid_for(std::max<long long>(total, 1), 256)), dim3(256), 0, st, D.status, D.pool,

@@ -587,7 +587,9 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     auto solve_kind = [&](i32 s) {
         if (order_r(s) <= 64) return (int) SK_SMALL;
         if (order_r(s) <= 128 && width(s) <= 64) return (int) SK_WAVE;
-        return (width(s) > 64 && order_r(s) > 136) ? (int) SK_BIG : (int) SK_BLOCK;
+        // wide big fronts: one launch per chunk with many workgroups for a lone matrix; a batch fills the chip with one
+        // workgroup per (front, matrix), so there the single-launch block kernel is the shorter path
+        return (width(s) > 64 && order_r(s) > 136 && S.batch < 16) ? (int) SK_BIG : (int) SK_BLOCK;
     };
     S.bv_off.assign(ns, 0); S.bv_size = 0;
     for (i32 s = 0; s < ns; ++s)

@@ -109,7 +109,8 @@ class _Phases:
 
 
 def solve_many_rhs(backend, Ax, B, tol=0.0, group=None, root=0, timings=None, sync=None):
-    """Config 4: A X = B with B [n, k] known on `root`; returns X [n, k] on root, None elsewhere.
+    """Config 4: A X = B with B [n, k] known on `root` (a NumPy array, or a torch tensor already in HBM);
+    returns X [n, k] on root, None elsewhere.
 
     Collectives: one broadcast of the factor panels, one gather of the solution slabs; the RHS slabs leave the
     root as one batch of point-to-point sends (every xGMI link of the root busy at once).
@@ -148,6 +149,8 @@ def solve_many_rhs(backend, Ax, B, tol=0.0, group=None, root=0, timings=None, sy
         _scatter_uneven(mine, slabs, root, group)
     else:
         mine = backend.to_device(B).contiguous()
+        if isinstance(B, torch.Tensor) and mine.data_ptr() == B.data_ptr():
+            mine = mine.clone()                      # the sweeps run in place; the caller keeps its right-hand sides
     ph.mark("scatter")
     if hi > lo:
         backend.solve(mine)

@@ -22,6 +22,14 @@ def hip():
 
 @pytest.fixture(scope="session")
 def gpu(hip):
+    # torch brings its own copy of the HIP runtime; the tests that use torch tensors for device buffers need it
+    # initialised in this process too, and doing that first keeps the order independent of test selection
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     if hip.device_count() < 1:
         pytest.fail("no HIP device visible: gpu-marked tests must run on the GPU box")
     return hip

@@ -230,6 +230,60 @@ def test_batch_of_matrices_sharing_a_pattern(gpu, orc):
                 assert np.abs(A @ X[i] - B[i]).max() <= 1e-11 * n
 
 
+@pytest.mark.parametrize("chol", [False, True])
+@pytest.mark.parametrize("nd", [150, 260])
+def test_batched_big_fronts_in_one_workgroup(gpu, orc, chol, nd):
+    """A batch of 16 or more matrices sends fronts beyond the LDS to k_front_wg (one workgroup per front and
+    matrix, one launch) and their sweeps to the single-launch block kernels: every matrix must match the oracle
+    and the same matrix factorised alone (multi-launch path)."""
+    import scipy.sparse as sp
+    m, n, Ap, Ai, Ax = synth.dense_block_matrix(n=nd + 350, nd=nd, seed=nd)
+    kind = gpu.CS3_LU
+    if chol:
+        A = sp.csc_matrix((Ax, Ai, Ap), shape=(n, n))
+        S = (A + A.T).tocsc(); S.sort_indices()
+        Ap, Ai, Ax = S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.copy()
+        kind = gpu.CS3_CHOLESKY
+    nb = 18
+    rng = np.random.default_rng(nd)
+    AX = Ax[None, :] * (1.0 + 0.03 * rng.uniform(-1.0, 1.0, size=(nb, len(Ax))))
+    if chol:                                           # keep the perturbed matrices symmetric: scale whole matrices instead
+        AX = Ax[None, :] * (1.0 + rng.uniform(0.0, 1.0, size=(nb, 1)))
+    B = rng.standard_normal((nb, n, 2))
+    with gpu.Factorization(m, n, Ap, Ai, kind=kind, batch=nb) as F:
+        assert F.info.max_front >= nd
+        F.factor(AX, 1e-3 if not chol else 0.0)
+        X = F.solve(B)
+        q = F.ordering()["q"]
+        facs = {i: F.factors(b=i) for i in (0, 7, nb - 1)}
+        F.factor(AX, 1e-3 if not chol else 0.0)
+        assert np.array_equal(F.solve(B), X)                              # run-to-run bitwise
+    for i, (Lp, Li, Lx, Up, Ui, Ux) in facs.items():
+        if chol:
+            assert_factor_equal(n, (Lp, Li, Lx), _oracle_chol(orc, n, Ap, Ai, AX[i], q), "batched big chol %d" % i)
+        else:
+            oL = orc.csc_lu_f(n, n, Ap, Ai, AX[i], q, 1e-3)
+            assert_factor_equal(n, (Lp, Li, Lx), oL[0:3], "batched big L %d" % i)
+            assert_factor_equal(n, (Up, Ui, Ux), oL[3:6], "batched big U %d" % i)
+    for i in range(nb):
+        A = csc_to_scipy(m, n, Ap, Ai, AX[i])
+        assert np.abs(A @ X[i] - B[i]).max() <= 1e-11 * n * max(1.0, np.abs(X[i]).max())
+    with gpu.Factorization(m, n, Ap, Ai, kind=kind) as G:
+        G.factor(AX[7], 1e-3 if not chol else 0.0)
+        assert rel_err(X[7], G.solve(B[7])) <= 1e-12
+    # a rejected pivot inside a big front of ONE matrix of the batch is reported
+    if not chol:
+        bad = AX.copy()
+        rows = Ai[:Ap[n]]; cols = np.repeat(np.arange(n), np.diff(Ap))
+        last = q[-1]
+        bad[5, (rows == cols) & (cols == last)] = 0.0
+        bad[5, (rows == last) | (cols == last)] = 0.0                     # a zero row and column: the last pivot is exactly zero
+        with gpu.Factorization(m, n, Ap, Ai, kind=kind, batch=nb) as F:
+            with pytest.raises(gpu.SingularMatrix):
+                F.factor(bad, 1e-3)
+            assert F.info.fail_col == n - 1
+
+
 # ------------------------------------------- full-size, size-independent ----
 
 def test_config3_full_size_properties(gpu):

@@ -77,7 +77,7 @@ void release_device(cs3_handle h)
     h->fj.destroy();
     void **ptrs[] = {(void **) &D.fdesc, (void **) &D.st_idx, (void **) &D.asm_src, (void **) &D.asm_tgt, (void **) &D.long_src,
                      (void **) &D.sdesc, (void **) &D.fasm_src, (void **) &D.fasm_tgt, (void **) &D.flong_src, (void **) &D.rl_pairs,
-                     (void **) &D.q, (void **) &D.ax, (void **) &D.pool, (void **) &D.dbuf, (void **) &D.tbuf, (void **) &D.bigv,
+                     (void **) &D.q, (void **) &D.ila_pairs, (void **) &D.ax, (void **) &D.pool, (void **) &D.dbuf, (void **) &D.tbuf, (void **) &D.bigv,
                      (void **) &D.cv, (void **) &D.xp, (void **) &D.status, (void **) &h->d_lmap, (void **) &h->d_umap,
                      (void **) &h->d_lx, (void **) &h->d_ux};
     for (void **p : ptrs) if (*p) { (void) hipFree(*p); *p = nullptr; }
@@ -120,6 +120,7 @@ int ensure_device_impl(cs3_handle h)
         FrontDesc &f = fdesc[t];
         f.lpan = S.lpan_off[s]; f.upan = S.upan_off[s]; f.cb = S.cb_off[s];
         f.asm_begin = S.asm_ptr[s]; f.asm_count = (int) (S.asm_ptr[s + 1] - S.asm_ptr[s]);
+        if (S.sn_class[s] == FC_IL) { f.asm_begin = S.ila_ptr[s]; f.asm_count = (int) (S.ila_ptr[s + 1] - S.ila_ptr[s]); }
         f.c0 = S.sn_ptr[s];
         f.r = (int) (S.st_ptr[s + 1] - S.st_ptr[s]);
         f.w = S.sn_ptr[s + 1] - S.sn_ptr[s];
@@ -155,7 +156,14 @@ int ensure_device_impl(cs3_handle h)
     if ((rc = upload(&D.asm_tgt, S.asm_tgt))) return rc;
     if ((rc = upload(&D.long_src, S.long_src))) return rc;
     if ((rc = upload(&D.q, S.q))) return rc;
-    CS3_HIP(hipMalloc((void **) &D.pool, ((size_t) (D.batch * D.pool_size) + POOL_SLACK) * sizeof(double)));   // slack: see k_fwd_rhs
+    if ((rc = upload(&D.ila_pairs, S.ila_pairs))) return rc;
+    D.il_len = S.il_len;
+    D.pm_stride = S.pool_size - S.il_len;
+    D.ngroups = (D.batch + 63) / 64;
+    const size_t il_doubles = (size_t) (D.ngroups * 64 * D.il_len);
+    CS3_HIP(hipMalloc((void **) &D.pool, (il_doubles + (size_t) (D.batch * D.pm_stride) + POOL_SLACK) * sizeof(double)));   // slack: see k_fwd_rhs
+    D.pool_il = D.pool;
+    D.pool_pm = D.pool + il_doubles - D.il_len;            // virtual offsets >= il_len index this pointer directly
     CS3_HIP(hipMalloc((void **) &D.dbuf, std::max<size_t>(1, (size_t) (D.batch * D.dbuf_size)) * sizeof(double)));
     CS3_HIP(hipMalloc((void **) &D.ax, std::max<size_t>(1, (size_t) (D.batch * D.nnz_a)) * sizeof(double)));
     CS3_HIP(hipMalloc((void **) &D.status, sizeof(int)));
@@ -576,6 +584,7 @@ int cs3_export_factor_dev(cs3_handle h, double *dst_dev, void *stream)
     if (!h->factored) { set_error("cs3_export_factor_dev: nothing factorised"); return CS3_ERR_STATE; }
     if (!dst_dev) { set_error("cs3_export_factor_dev: null buffer"); return CS3_ERR_ARG; }
     const DeviceFactor &D = h->D;
+    if (D.il_len > 0) { set_error("cs3_export_factor_dev: not available for a matrix-interleaved batch (64 or more matrices)"); return CS3_ERR_STATE; }
     if (D.vals_size > 0)
         CS3_HIP(hipMemcpy2DAsync(dst_dev, (size_t) D.vals_size * sizeof(double), D.pool,
                                  (size_t) D.pool_size * sizeof(double), (size_t) D.vals_size * sizeof(double),
@@ -589,6 +598,7 @@ int cs3_import_factor_dev(cs3_handle h, const double *src_dev, void *stream)
     if (!src_dev) { set_error("cs3_import_factor_dev: null buffer"); return CS3_ERR_ARG; }
     if ((rc = ensure_device(h))) return rc;
     const DeviceFactor &D = h->D;
+    if (D.il_len > 0) { set_error("cs3_import_factor_dev: not available for a matrix-interleaved batch (64 or more matrices)"); return CS3_ERR_STATE; }
     if (D.vals_size > 0)
         CS3_HIP(hipMemcpy2DAsync(D.pool, (size_t) D.pool_size * sizeof(double), src_dev,
                                  (size_t) D.vals_size * sizeof(double), (size_t) D.vals_size * sizeof(double),
@@ -635,17 +645,19 @@ int cs3_get_factors(cs3_handle h, int64_t b, int32_t *Lp, int32_t *Li, double *L
     if (Ui) std::memcpy(Ui, S.Ui.data(), (size_t) unz * sizeof(int32_t));
     if (!Lx && !Ux) return CS3_OK;
     if (!h->factored) { set_error("cs3_get_factors: values requested before a successful factorisation"); return CS3_ERR_STATE; }
-    const double *vals = h->D.pool + b * h->D.pool_size;
+    const DeviceFactor &DD = h->D;
+    const double *vals = DD.pool_pm + b * DD.pm_stride;                                   // per-matrix part (virtual offsets)
+    const double *vals_il = DD.pool_il + (b / 64) * 64 * DD.il_len + (b % 64);          // interleaved part, stride 64
     if (Lx) {
         if (!h->d_lmap) { if ((rc = upload(&h->d_lmap, S.Lmap))) return rc; }
         if (!h->d_lx) CS3_HIP(hipMalloc((void **) &h->d_lx, std::max<size_t>(1, (size_t) lnz) * sizeof(double)));
-        CS3_HIP(launch_extract(vals, (const long long *) h->d_lmap, h->d_lx, lnz, nullptr));
+        CS3_HIP(launch_extract(vals, vals_il, DD.il_len, (const long long *) h->d_lmap, h->d_lx, lnz, nullptr));
         CS3_HIP(hipMemcpy(Lx, h->d_lx, (size_t) lnz * sizeof(double), hipMemcpyDeviceToHost));
     }
     if (Ux) {
         if (!h->d_umap) { if ((rc = upload(&h->d_umap, S.Umap))) return rc; }
         if (!h->d_ux) CS3_HIP(hipMalloc((void **) &h->d_ux, std::max<size_t>(1, (size_t) unz) * sizeof(double)));
-        CS3_HIP(launch_extract(vals, (const long long *) h->d_umap, h->d_ux, unz, nullptr));
+        CS3_HIP(launch_extract(vals, vals_il, DD.il_len, (const long long *) h->d_umap, h->d_ux, unz, nullptr));
         CS3_HIP(hipMemcpy(Ux, h->d_ux, (size_t) unz * sizeof(double), hipMemcpyDeviceToHost));
     }
     return CS3_OK;

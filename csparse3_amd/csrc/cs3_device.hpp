@@ -51,7 +51,13 @@ struct DeviceFactor {
     int *rl_pairs = nullptr;
     int *q = nullptr;             // [n] pivot order
     double *ax = nullptr;         // [batch][nnz_a] values of A (stable address for the graph)
-    double *pool = nullptr;       // [batch][pool_size]  factors | contribution blocks
+    double *pool = nullptr;       // the allocation: [groups][il_len][64] interleaved block, then [batch][pm_stride]
+    // What the kernels see.  A pool offset `off` is VIRTUAL: off < il_len lives in the matrix-interleaved block
+    // (entry off of matrix m at pool_il[(m / 64) * 64 * il_len + off * 64 + m % 64]), anything else at
+    // pool_pm[m * pm_stride + off] -- pool_pm is shifted by -il_len so that virtual offsets index it directly.
+    double *pool_il = nullptr, *pool_pm = nullptr;
+    long long il_len = 0, pm_stride = 0, ngroups = 1;
+    int *ila_pairs = nullptr;     // assembly pairs of the FC_IL fronts
     double *dbuf = nullptr;       // [batch][dbuf_size] diagonal blocks of the big fronts in flight
     long long dbuf_size = 0;
     double *cv = nullptr;         // [batch][cv_size * nrhs_cap]
@@ -61,6 +67,12 @@ struct DeviceFactor {
     long long nrhs_cap = 0;
     int *status = nullptr;        // [1] first failing pivot column, 0x7f7f7f7f when clean
     long long *tbuf = nullptr;    // diagnostics (CS3_PROFILE=1): 8 shader-clock stamps per front, schedule order
+};
+
+// The interleaved block as a kernel argument (by value).
+struct IlView {
+    double *base;                 // DeviceFactor::pool_il
+    long long len;                // DeviceFactor::il_len (0: no interleaved region)
 };
 
 // Side streams and events used to run the independent launches of one tree level
@@ -92,8 +104,8 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
 hipError_t launch_prologue(const DeviceFactor &D, const double *ax_src, const double *x_src, int nrhs, hipStream_t st);
 hipError_t launch_permute(const DeviceFactor &D, const double *src, double *dst, int nrhs, bool scatter,
                           hipStream_t st);
-hipError_t launch_extract(const double *vals, const long long *map, double *out, long long count,
-                          hipStream_t st);
+hipError_t launch_extract(const double *vals, const double *vals_il, long long il_len, const long long *map, double *out,
+                          long long count, hipStream_t st);
 hipError_t launch_tri_level(const int *rows, int nrows, const int *Rp, const int *Rj, const long long *Rmap,
                             const long long *diag, const double *Gx, double *X, int nrhs, hipStream_t st);
 hipError_t launch_stack_4_by_4(int an, int bn, int am, int bm, const int *Ap, const int *Ai, const double *Ax,

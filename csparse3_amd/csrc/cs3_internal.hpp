@@ -30,7 +30,8 @@ void cholesky_counts(i64 n, const i32 *Ap, const i32 *Ai, const i32 *parent,
                      const i32 *post, i32 *colcount);
 
 // Size classes of fronts; each class is one kernel configuration.
-enum FrontClass : int { FC_R16 = 0, FC_R32 = 1, FC_R64 = 2, FC_LDS = 3, FC_BIG = 4, FC_COUNT = 5 };
+// FC_IL: small fronts of a large batch, stored matrix-interleaved and processed lane = matrix (k_front_il).
+enum FrontClass : int { FC_R16 = 0, FC_R32 = 1, FC_R64 = 2, FC_LDS = 3, FC_BIG = 4, FC_IL = 5, FC_COUNT = 6 };
 
 // Solve kernels by front shape.  SK_SMALL and SK_WAVE share the one-wave-per-front kernels for few
 // right-hand sides (adjacent in the schedule, launched as one group); with many right-hand sides
@@ -39,7 +40,8 @@ enum SolveKind : int {
     SK_SMALL = 0,      // r <= 64
     SK_WAVE = 1,       // r <= 128, w <= 64
     SK_BLOCK = 2,      // one workgroup per front
-    SK_BIG = 3         // w > 64, r > 136: one launch per 64-column chunk, many workgroups
+    SK_BIG = 3,        // w > 64, r > 136: one launch per 64-column chunk, many workgroups
+    SK_IL = 4          // matrix-interleaved small fronts of a large batch: lane = matrix (k_fwd_il / k_bwd_il)
 };
 
 struct LaunchGroup {          // fronts of one level that share a kernel configuration
@@ -78,6 +80,14 @@ struct Symbolic {
     std::vector<i64> rel_ptr;                 // [nsuper+1] into rel_idx (length r - w each)
     std::vector<i32> rel_idx;                 // position of my update rows in the parent's structure
     i64 vals_size = 0, cb_size = 0, cv_size = 0, pool_size = 0;
+    // Matrix-interleaved region (batches of 64 or more): the dense r x r buffers of the FC_IL fronts occupy the
+    // VIRTUAL offsets [0, il_len); entry `off` of matrix m lives at  group(m) * 64 * il_len + off * 64 + m % 64
+    // of the interleaved block, so that one front entry of 64 matrices is one 512-byte access.  Offsets
+    // >= il_len are per-matrix as before.  il_len = 0: no interleaved region.
+    i64 il_len = 0;
+    std::vector<i64> ila_ptr;                 // [nsuper+1] into ila_pairs (pairs; FC_IL fronts only)
+    std::vector<i32> ila_pairs;               // (front-local target, source) sorted by target; EVERY stored entry of the
+                                              //   front appears: source >= 0 pool offset, < 0 entry ~src of Ax, IL_ZERO none
     i64 big_begin = 0;                        // big-front buffers occupy [big_begin, vals_size)
     // assembly: every front entry = sum of its sources (A entries, children's
     // contribution blocks), listed sorted by target.  src >= 0: pool offset;
@@ -109,6 +119,10 @@ struct Symbolic {
     double t_order = 0.0, t_symbolic = 0.0;
 };
 
+constexpr i32 IL_ZERO = INT32_MIN;            // ila_pairs source: this entry has no source (starts at zero)
+constexpr i32 IL_RMAX = 32;                   // largest front order the lane = matrix kernels take (LDS vector of the sweeps)
+constexpr i32 IL_RMAX_DEFAULT = 16;           // ... and the largest that is sent there (CS3_IL_RMAX): beyond it a front of 64
+                                              //   matrices no longer stays in cache between passes and lane = row wins
 constexpr i32 ASM_DUMMY = 0x3fffffff;         // padding target: contributes nowhere
 constexpr i32 ASM_LONG = 0x40000000;          // flag on a target: sources are long_src[src .. src+count)
 

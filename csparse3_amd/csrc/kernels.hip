@@ -70,6 +70,12 @@ __device__ __forceinline__ double bcast_lane(double x, int k)     // k wave-unif
     return __hiloint2double(hi, lo);
 }
 
+// Interleaved block: entry `off` (< il.len) of matrix m is  il_lane_base(il, m)[off * 64].
+__device__ __forceinline__ double *il_lane_base(const IlView &il, long long m)
+{
+    return il.base + (m >> 6) * 64 * il.len + (m & 63);
+}
+
 constexpr int ASM_DUMMY_T = 0x3fffffff;
 constexpr int ASM_LONG_T = 0x40000000;
 constexpr int GATHER_UNROLL = 4;
@@ -199,9 +205,10 @@ __device__ __forceinline__ void
 front_lds_body(const FrontDesc &d, int first, double *F,
                const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
                const double *__restrict__ ax_all, double *__restrict__ pool_all,
-               long long nnz_a, long long pool_stride, double inv_tol, int *status, long long *tbuf, long long t_start)
+               long long nnz_a, long long pool_stride, IlView il, double inv_tol, int *status, long long *tbuf, long long t_start)
 {
     constexpr int TY = THREADS / TX;
+    const double *pil = il_lane_base(il, blockIdx.y);
 #define CS3_STAMP(p) do { if (tbuf && threadIdx.x == 0) tbuf[(long long) (first + blockIdx.x) * 8 + (p)] = (long long) __builtin_amdgcn_s_memtime() - t_start; } while (0)
     const double *ax = ax_all + (long long) blockIdx.y * nnz_a;
     double *pool = pool_all + (long long) blockIdx.y * pool_stride;
@@ -217,7 +224,7 @@ front_lds_body(const FrontDesc &d, int first, double *F,
     CS3_STAMP(1);
     gather_front(d.asm_begin, d.asm_count >> 6, (tid >> 6) * GATHER_UNROLL, (THREADS / 64) * GATHER_UNROLL,
                  asm_src, asm_tgt, long_src,
-                 [&](int q) -> const double * { return (q >= 0) ? pool + q : ax + ~q; },
+                 [&](int q) -> const double * { return (q >= 0) ? ((q < il.len) ? pil + (long long) q * 64 : pool + q) : ax + ~q; },
                  [&](int t, double v) { F[t] = v; });
     __syncthreads();
     CS3_STAMP(2);
@@ -327,9 +334,10 @@ __device__ __forceinline__ void
 front_wave_body(const FrontDesc &d, int first, double *F,
                 const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
                 const double *__restrict__ ax_all, double *__restrict__ pool_all,
-                long long nnz_a, long long pool_stride, double inv_tol, int *status, long long *tbuf, long long t_start)
+                long long nnz_a, long long pool_stride, IlView il, double inv_tol, int *status, long long *tbuf, long long t_start)
 {
 #define CS3_STAMP(p) do { if (tbuf && threadIdx.x == 0) tbuf[(long long) (first + blockIdx.x) * 8 + (p)] = (long long) __builtin_amdgcn_s_memtime() - t_start; } while (0)
+    const double *pil = il_lane_base(il, blockIdx.y);
     const double *ax = ax_all + (long long) blockIdx.y * nnz_a;
     double *pool = pool_all + (long long) blockIdx.y * pool_stride;
     const int r = d.r, w = d.w, nb = r - w;
@@ -342,7 +350,7 @@ front_wave_body(const FrontDesc &d, int first, double *F,
     CS3_STAMP(1);
     gather_front(d.asm_begin, d.asm_count >> 6, (threadIdx.x >> 6) * GATHER_UNROLL, nwaves * GATHER_UNROLL,
                  asm_src, asm_tgt, long_src,
-                 [&](int q) -> const double * { return (q >= 0) ? pool + q : ax + ~q; },
+                 [&](int q) -> const double * { return (q >= 0) ? ((q < il.len) ? pil + (long long) q * 64 : pool + q) : ax + ~q; },
                  [&](int t, double v) { F[t] = v; });
     __syncthreads();
     CS3_STAMP(2);
@@ -474,12 +482,12 @@ __global__ void __launch_bounds__(64)
 k_front_wave(const FrontDesc *__restrict__ fdesc, int first,
              const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
              const double *__restrict__ ax_all, double *__restrict__ pool_all,
-             long long nnz_a, long long pool_stride, double inv_tol, int *status, long long *tbuf)
+             long long nnz_a, long long pool_stride, IlView il, double inv_tol, int *status, long long *tbuf)
 {
     extern __shared__ __attribute__((aligned(16))) double F[];
     const long long t_start = tbuf ? (long long) __builtin_amdgcn_s_memtime() : 0;
     const FrontDesc d = fdesc[first + blockIdx.x];
-    front_wave_body<KIND, 32>(d, first, F, asm_src, asm_tgt, long_src, ax_all, pool_all, nnz_a, pool_stride,
+    front_wave_body<KIND, 32>(d, first, F, asm_src, asm_tgt, long_src, ax_all, pool_all, nnz_a, pool_stride, il,
                               inv_tol, status, tbuf, t_start);
 }
 
@@ -490,17 +498,17 @@ __global__ void __launch_bounds__(256)
 k_front_mix(const FrontDesc *__restrict__ fdesc, int first,
             const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
             const double *__restrict__ ax_all, double *__restrict__ pool_all,
-            long long nnz_a, long long pool_stride, double inv_tol, int *status, long long *tbuf)
+            long long nnz_a, long long pool_stride, IlView il, double inv_tol, int *status, long long *tbuf)
 {
     extern __shared__ __attribute__((aligned(16))) double F[];
     const long long t_start = tbuf ? (long long) __builtin_amdgcn_s_memtime() : 0;
     const FrontDesc d = fdesc[first + blockIdx.x];
     if (d.r <= 32)
-        front_wave_body<KIND, 32>(d, first, F, asm_src, asm_tgt, long_src, ax_all, pool_all, nnz_a, pool_stride,
+        front_wave_body<KIND, 32>(d, first, F, asm_src, asm_tgt, long_src, ax_all, pool_all, nnz_a, pool_stride, il,
                                   inv_tol, status, tbuf, t_start);
     else
         front_lds_body<KIND, 256, 16, 4, 4>(d, first, F, asm_src, asm_tgt, long_src, ax_all, pool_all, nnz_a,
-                                            pool_stride, inv_tol, status, tbuf, t_start);
+                                            pool_stride, il, inv_tol, status, tbuf, t_start);
 }
 
 // ------------------------------------------- front too large for the LDS --
@@ -514,15 +522,16 @@ __global__ void __launch_bounds__(256)
 k_big_gather(const FrontDesc *__restrict__ fdesc, int first,
              const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
              const double *__restrict__ ax_all, double *__restrict__ pool_all,
-             long long nnz_a, long long pool_stride)
+             long long nnz_a, long long pool_stride, IlView il)
 {
     const FrontDesc d = fdesc[first + blockIdx.z];
+    const double *pil = il_lane_base(il, blockIdx.y);
     const double *ax = ax_all + (long long) blockIdx.y * nnz_a;
     double *pool = pool_all + (long long) blockIdx.y * pool_stride;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     gather_front(d.asm_begin, d.asm_count >> 6, wave * GATHER_UNROLL, gridDim.x * 4 * GATHER_UNROLL,
                  asm_src, asm_tgt, long_src,
-                 [&](int q) -> const double * { return (q >= 0) ? pool + q : ax + ~q; },
+                 [&](int q) -> const double * { return (q >= 0) ? ((q < il.len) ? pil + (long long) q * 64 : pool + q) : ax + ~q; },
                  [&](int t, double v) { pool[t] = v; });
 }
 
@@ -584,9 +593,10 @@ __global__ void __launch_bounds__(512)
 k_front_block(const FrontDesc *__restrict__ fdesc, int first,
               const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
               const double *__restrict__ ax_all, double *__restrict__ pool_all,
-              long long nnz_a, long long pool_stride, double inv_tol, int *status, long long *tbuf)
+              long long nnz_a, long long pool_stride, IlView il, double inv_tol, int *status, long long *tbuf)
 {
     extern __shared__ __attribute__((aligned(16))) double F[];
+    const double *pil = il_lane_base(il, blockIdx.y);
     const long long t_start = tbuf ? (long long) __builtin_amdgcn_s_memtime() : 0;
 #define CS3_STAMP(p) do { if (tbuf && threadIdx.x == 0) tbuf[(long long) (first + blockIdx.x) * 8 + (p)] = (long long) __builtin_amdgcn_s_memtime() - t_start; } while (0)
     const FrontDesc d = fdesc[first + blockIdx.x];
@@ -603,7 +613,7 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
     __syncthreads();
     CS3_STAMP(1);
     gather_front(d.asm_begin, d.asm_count >> 6, wv * GATHER_UNROLL, 8 * GATHER_UNROLL, asm_src, asm_tgt, long_src,
-                 [&](int q) -> const double * { return (q >= 0) ? pool + q : ax + ~q; },
+                 [&](int q) -> const double * { return (q >= 0) ? ((q < il.len) ? pil + (long long) q * 64 : pool + q) : ax + ~q; },
                  [&](int t, double v) { F[t] = v; });
     __syncthreads();
     CS3_STAMP(2);
@@ -741,9 +751,10 @@ __global__ void __launch_bounds__(512)
 k_front_wg(const FrontDesc *__restrict__ fdesc, int first,
            const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
            const double *__restrict__ ax_all, double *__restrict__ pool_all,
-           long long nnz_a, long long pool_stride, double inv_tol, int *status, int pld, long long *tbuf)
+           long long nnz_a, long long pool_stride, IlView il, double inv_tol, int *status, int pld, long long *tbuf)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    const double *pil = il_lane_base(il, blockIdx.y);
     // diagnostics (CS3_PROFILE=1), matrix 0 of the batch: slot 0 zeroed, 1 gathered, 2 sum of the panel phases,
     // 3 sum of the update phases, 4 block steps, 5 end -- shader-clock cycles
     const bool prof = tbuf && blockIdx.y == 0 && threadIdx.x == 0;
@@ -767,7 +778,7 @@ k_front_wg(const FrontDesc *__restrict__ fdesc, int first,
     __syncthreads();
     CS3_WSTAMP(0);
     gather_front(d.asm_begin, d.asm_count >> 6, wv * GATHER_UNROLL, 8 * GATHER_UNROLL, asm_src, asm_tgt, long_src,
-                 [&](int q) -> const double * { return (q >= 0) ? pool + q : ax + ~q; },
+                 [&](int q) -> const double * { return (q >= 0) ? ((q < il.len) ? pil + (long long) q * 64 : pool + q) : ax + ~q; },
                  [&](int t, double v) { pool[t] = v; });
     __syncthreads();
     CS3_WSTAMP(1);
@@ -2014,6 +2025,328 @@ k_bwd_big_step(const SolveDesc *__restrict__ sd, int first, int chunk_from_right
         v[row] -= ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
 }
 
+// ============================================================ lane = matrix ==
+// Batches of 64 or more matrices that share a pattern: the fronts of order <= 32 (nine in ten of all
+// fronts, and most of the factor entries of a power-grid matrix) are stored MATRIX-INTERLEAVED -- entry e of the
+// dense r x r buffer of a front, for the 64 matrices of a group, is 64 consecutive doubles -- and one wave
+// owns one front of one GROUP: lane = matrix.  Every lane runs the same scalar algorithm on its own matrix:
+// no cross-lane traffic in the data, every access of the wave is one coalesced 512-byte line set, and the index
+// lists (which are the same for all matrices) are read once per 64 matrices instead of once per matrix.  With
+// one wave per (front, matrix) these fronts are instruction- and latency-bound (three dependent memory rounds
+// and a 32-step padded elimination for a front that holds 100 entries).
+//   * assembly: (target, source) pairs sorted by target in which every stored entry of the front appears
+//     (Symbolic::ila_pairs); a run is summed in a register and stored once.  Sources in the interleaved block
+//     are coalesced; A entries and contribution blocks of larger children are per-matrix (strided over the lanes).
+//   * factorisation: right-looking, IL_KB pivots per step, in place in the interleaved buffer (which sits in
+//     this CU's L1 / the XCD's L2); registers hold one tile at a time, statically indexed: the diagonal block,
+//     then 8-row strips of the block column (the triangular solve X U11 = T by substitution), 8-column strips of
+//     the block row (LU), then the 8 x 8 tiles of the trailing matrix with the rank-IL_KB update.
+// Dead lanes of the last group shadow the group's first matrix and store into their own (allocated) slots.
+constexpr int IL_KB = 4;
+constexpr int IL_T = 8;        // rows per strip / tile
+constexpr int IL_TJ = 4;       // columns per tile of the trailing update
+constexpr int IL_NONE = INT32_MIN;             // pair source: no source (cs3::IL_ZERO)
+
+template <int KIND>
+__global__ void __launch_bounds__(64)
+k_front_il(const FrontDesc *__restrict__ fdesc, int first, const int *__restrict__ pairs,
+           const double *__restrict__ ax_all, long long nnz_a, IlView il,
+           const double *__restrict__ pool_pm_all, long long pm_stride, int batch, double inv_tol, int *status)
+{
+    const FrontDesc d = fdesc[first + blockIdx.x];
+    const int lane = threadIdx.x;
+    const long long m = (long long) blockIdx.y * 64 + lane;
+    const bool live = m < batch;
+    const long long mm = live ? m : (long long) blockIdx.y * 64;
+    double *G = il.base + (long long) blockIdx.y * 64 * il.len + lane;        // entry off of my matrix: G[off * 64]
+    const double *P = pool_pm_all + mm * pm_stride;                           // per-matrix part, virtual offsets
+    const double *ax = ax_all + mm * nnz_a;
+    const int r = d.r, w = d.w;
+    double *F = G + d.lpan * 64;                                              // element (i, j) of the front: F[(i + j r) 64]
+#define EL(i, j) F[((long long) (i) + (long long) (j) * r) * 64]
+
+    // ---- assembly: sum every run of equal targets in a register, store it once
+    {
+        const int np = d.asm_count;                                           // multiple of 16
+        const int *pr = pairs + 2 * d.asm_begin;
+        int cur = -1;
+        double acc = 0.0;
+        for (int base = 0; base < np; base += 64) {
+            const int have = min(64, np - base);
+            const int e = base + (lane < have ? lane : 0);
+            const int ptg = pr[2 * e], psr = pr[2 * e + 1];                   // pair `lane` of this block of 64
+            for (int c = 0; c < have; c += 16) {
+                double val[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int sr = bcast_lane_i(psr, c + u);                  // wave-uniform
+                    const bool none = sr == IL_NONE;
+                    const int sc = none ? 0 : sr;
+                    const double *p = (sc >= 0) ? ((sc < il.len) ? (const double *) (G + (long long) sc * 64) : P + sc) : ax + ~sc;
+                    const double v = *p;
+                    val[u] = none ? 0.0 : v;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int tg = bcast_lane_i(ptg, c + u);
+                    if (tg != cur) {                                          // wave-uniform
+                        if (cur >= 0) F[(long long) cur * 64] = acc;
+                        cur = tg; acc = 0.0;
+                    }
+                    acc += (tg >= 0) ? val[u] : 0.0;
+                }
+            }
+        }
+        if (cur >= 0) F[(long long) cur * 64] = acc;
+    }
+
+    // ---- factorisation in place
+    bool bad = false;
+    int bad_col = 0;
+    for (int k0 = 0; k0 < w; k0 += IL_KB) {
+        const int kb = min(IL_KB, w - k0), ke = k0 + kb;
+        // 1. diagonal block, identity-padded past kb: dd[jj][ii] = element (k0 + ii, k0 + jj)
+        double dd[IL_KB][IL_KB], rd[IL_KB];
+#pragma unroll
+        for (int jj = 0; jj < IL_KB; ++jj)
+#pragma unroll
+            for (int ii = 0; ii < IL_KB; ++ii) {
+                const bool in = ii < kb && jj < kb && (KIND == CS3_LU || ii >= jj);
+                const double v = EL(in ? k0 + ii : k0, in ? k0 + jj : k0);
+                dd[jj][ii] = in ? v : ((ii == jj) ? 1.0 : 0.0);
+            }
+#pragma unroll
+        for (int kk = 0; kk < IL_KB; ++kk) {
+            const double piv = dd[kk][kk];
+            const double dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
+            bool rej = (KIND == CS3_LU) ? (!(fabs(piv) > 0.0) || !(fabs(piv) < 1.0e300)) : !(piv > 0.0);
+            rd[kk] = fast_rcp(dg);
+            if (KIND == CS3_CHOLESKY) dd[kk][kk] = (piv > 0.0) ? dg : -1.0;
+#pragma unroll
+            for (int ii = kk + 1; ii < IL_KB; ++ii) {
+                dd[kk][ii] *= rd[kk];
+                if (KIND == CS3_LU) rej = rej || (ii < kb && !(fabs(dd[kk][ii]) <= inv_tol));
+            }
+            if (rej && kk < kb && !bad) { bad = true; bad_col = k0 + kk; }
+#pragma unroll
+            for (int jj = kk + 1; jj < IL_KB; ++jj)
+#pragma unroll
+                for (int ii = (KIND == CS3_LU ? kk + 1 : jj); ii < IL_KB; ++ii)
+                    dd[jj][ii] -= dd[kk][ii] * ((KIND == CS3_LU) ? dd[jj][kk] : dd[kk][jj]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < IL_KB; ++jj)
+#pragma unroll
+            for (int ii = 0; ii < IL_KB; ++ii)
+                if (ii < kb && jj < kb && (KIND == CS3_LU || ii >= jj)) EL(k0 + ii, k0 + jj) = dd[jj][ii];
+        // 2. block column below the block, 8 rows at a time:  x U11 = t  (Cholesky: x L11' = t) by substitution
+        for (int i0 = ke; i0 < r; i0 += IL_T) {
+            double t[IL_T][IL_KB];
+#pragma unroll
+            for (int a = 0; a < IL_T; ++a)
+#pragma unroll
+                for (int jj = 0; jj < IL_KB; ++jj) {
+                    const bool in = i0 + a < r && jj < kb;
+                    const double v = EL(in ? i0 + a : i0, in ? k0 + jj : k0);
+                    t[a][jj] = in ? v : 0.0;
+                }
+#pragma unroll
+            for (int a = 0; a < IL_T; ++a)
+#pragma unroll
+                for (int jj = 0; jj < IL_KB; ++jj) {
+                    double x = t[a][jj];
+#pragma unroll
+                    for (int kk = 0; kk < jj; ++kk) x -= t[a][kk] * ((KIND == CS3_LU) ? dd[jj][kk] : dd[kk][jj]);
+                    x *= rd[jj];
+                    t[a][jj] = x;
+                    if (KIND == CS3_LU && jj < kb && i0 + a < r && !(fabs(x) <= inv_tol) && !bad) { bad = true; bad_col = k0 + jj; }
+                }
+#pragma unroll
+            for (int a = 0; a < IL_T; ++a)
+#pragma unroll
+                for (int jj = 0; jj < IL_KB; ++jj)
+                    if (i0 + a < r && jj < kb) EL(i0 + a, k0 + jj) = t[a][jj];
+        }
+        // 3. block row right of the block (LU), 8 columns at a time:  L11 u = t, unit lower
+        if (KIND == CS3_LU) {
+            for (int j0 = ke; j0 < r; j0 += IL_T) {
+                double u[IL_T][IL_KB];
+#pragma unroll
+                for (int b = 0; b < IL_T; ++b)
+#pragma unroll
+                    for (int kk = 0; kk < IL_KB; ++kk) {
+                        const bool in = j0 + b < r && kk < kb;
+                        const double v = EL(in ? k0 + kk : k0, in ? j0 + b : k0);
+                        u[b][kk] = in ? v : 0.0;
+                    }
+#pragma unroll
+                for (int b = 0; b < IL_T; ++b)
+#pragma unroll
+                    for (int kk = 1; kk < IL_KB; ++kk) {
+                        double x = u[b][kk];
+#pragma unroll
+                        for (int k2 = 0; k2 < kk; ++k2) x -= dd[k2][kk] * u[b][k2];
+                        u[b][kk] = x;
+                    }
+#pragma unroll
+                for (int b = 0; b < IL_T; ++b)
+#pragma unroll
+                    for (int kk = 1; kk < IL_KB; ++kk)
+                        if (j0 + b < r && kk < kb) EL(k0 + kk, j0 + b) = u[b][kk];
+            }
+        }
+        // 4. trailing matrix, 8 x 4 tiles:  C -= L(I, block) U(block, J)   (Cholesky: lower tiles, L(J, block)')
+        for (int j0 = ke; j0 < r; j0 += IL_TJ) {
+            double uc[IL_TJ][IL_KB];
+#pragma unroll
+            for (int b = 0; b < IL_TJ; ++b)
+#pragma unroll
+                for (int kk = 0; kk < IL_KB; ++kk) {
+                    const bool in = j0 + b < r && kk < kb;
+                    const double v = (KIND == CS3_LU) ? EL(in ? k0 + kk : k0, in ? j0 + b : k0) : EL(in ? j0 + b : k0, in ? k0 + kk : k0);
+                    uc[b][kk] = in ? v : 0.0;
+                }
+            // Cholesky: only rows i >= j0 matter; start at the 8-row strip that holds row j0
+            const int i_first = (KIND == CS3_LU) ? ke : ke + ((j0 - ke) / IL_T) * IL_T;
+            for (int i0 = i_first; i0 < r; i0 += IL_T) {
+                double lr[IL_T][IL_KB], c[IL_TJ][IL_T];
+#pragma unroll
+                for (int a = 0; a < IL_T; ++a)
+#pragma unroll
+                    for (int kk = 0; kk < IL_KB; ++kk) {
+                        const bool in = i0 + a < r && kk < kb;
+                        const double v = EL(in ? i0 + a : k0, in ? k0 + kk : k0);
+                        lr[a][kk] = in ? v : 0.0;
+                    }
+#pragma unroll
+                for (int b = 0; b < IL_TJ; ++b)
+#pragma unroll
+                    for (int a = 0; a < IL_T; ++a) {
+                        const bool in = i0 + a < r && j0 + b < r;
+                        c[b][a] = EL(in ? i0 + a : k0, in ? j0 + b : k0);
+                    }
+#pragma unroll
+                for (int kk = 0; kk < IL_KB; ++kk)
+#pragma unroll
+                    for (int b = 0; b < IL_TJ; ++b)
+#pragma unroll
+                        for (int a = 0; a < IL_T; ++a) c[b][a] -= lr[a][kk] * uc[b][kk];
+#pragma unroll
+                for (int b = 0; b < IL_TJ; ++b)
+#pragma unroll
+                    for (int a = 0; a < IL_T; ++a)
+                        if (i0 + a < r && j0 + b < r) EL(i0 + a, j0 + b) = c[b][a];
+            }
+        }
+    }
+#undef EL
+    if (bad && live) flag_column(status, d.c0 + bad_col);
+}
+
+// Sweeps of the interleaved fronts, lane = matrix.  The front vector of every matrix sits in LDS (one column per
+// lane: conflict-free) and the recurrences run as plain dynamic loops -- one coalesced 512-byte load of a panel
+// entry (different in every lane), one LDS read-modify-write and one FMA per factor entry; nothing is unrolled over
+// the front, so the kernels stay small at full occupancy.  X and the contribution vectors stay per-matrix (a few
+// values per front: strided over the lanes).  RMAX bounds the front order (LDS: RMAX * 512 bytes per wave).
+template <int KIND, int RMAX>
+__global__ void __launch_bounds__(64)
+k_fwd_il(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ rl, IlView il,
+         double *cv_all, double *X_all, int nrhs, long long cv_stride, long long x_stride, int batch)
+{
+    __shared__ double vl[RMAX * 64];
+    const SolveDesc d = sd[first + blockIdx.x];
+    const int lane = threadIdx.x;
+    const long long m = (long long) blockIdx.y * 64 + lane;
+    const bool live = m < batch;
+    const long long mm = live ? m : (long long) blockIdx.y * 64;
+    const int r = d.r, w = d.w;
+    const double *L = il.base + (long long) blockIdx.y * 64 * il.len + lane + d.lpan * 64;     // (i, k): L[(i + k r) 64]
+    double *cv = cv_all + mm * cv_stride;
+    double *X = X_all + mm * x_stride;
+    double *v = vl + lane;                                                                      // entry t: v[t * 64]
+    for (int q = 0; q < nrhs; ++q) {
+#pragma unroll 8
+        for (int t = 0; t < w; ++t) v[t * 64] = X[(long long) (d.c0 + t) * nrhs + q];
+        for (int t = w; t < r; ++t) v[t * 64] = 0.0;
+        {
+            const int np = d.rl_count;                             // multiple of 16
+            const int *pr = rl + 2 * d.rl_begin;
+            int cur = -1;
+            double acc = 0.0;
+            for (int base = 0; base < np; base += 64) {
+                const int have = min(64, np - base);
+                const int e = base + (lane < have ? lane : 0);
+                const int ptg = pr[2 * e], psr = pr[2 * e + 1];
+                for (int c = 0; c < have; c += 16) {
+                    double val[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) val[u] = cv[(long long) bcast_lane_i(psr, c + u) * nrhs + q];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int tg = bcast_lane_i(ptg, c + u);
+                        if (tg != cur) {
+                            if (cur >= 0) v[cur * 64] += acc;
+                            cur = tg; acc = 0.0;
+                        }
+                        acc += (tg >= 0) ? val[u] : 0.0;
+                    }
+                }
+            }
+            if (cur >= 0) v[cur * 64] += acc;
+        }
+        for (int k = 0; k < w; ++k) {
+            const double *Lk = L + (long long) k * r * 64;
+            double vk = v[k * 64];
+            if (KIND == CS3_CHOLESKY) { vk *= fast_rcp(Lk[k * 64]); v[k * 64] = vk; }
+#pragma unroll 8
+            for (int i = k + 1; i < r; ++i) v[i * 64] -= Lk[i * 64] * vk;
+        }
+        if (live) {
+#pragma unroll 8
+            for (int t = 0; t < w; ++t) X[(long long) (d.c0 + t) * nrhs + q] = v[t * 64];
+            if (d.parent >= 0)
+                for (int t = w; t < r; ++t) cv[(d.cv + t - w) * nrhs + q] = v[t * 64];
+        }
+    }
+}
+
+template <int KIND, int RMAX>
+__global__ void __launch_bounds__(64)
+k_bwd_il(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ st_idx, IlView il,
+         double *X_all, int nrhs, long long x_stride, int batch)
+{
+    __shared__ double xl[RMAX * 64];
+    const SolveDesc d = sd[first + blockIdx.x];
+    const int lane = threadIdx.x;
+    const long long m = (long long) blockIdx.y * 64 + lane;
+    const bool live = m < batch;
+    const long long mm = live ? m : (long long) blockIdx.y * 64;
+    const int r = d.r, w = d.w;
+    const double *L = il.base + (long long) blockIdx.y * 64 * il.len + lane + d.lpan * 64;
+    double *X = X_all + mm * x_stride;
+    double *x = xl + lane;
+    // row of X behind front position `lane` (the same for every matrix)
+    const int myrow = (lane < w) ? d.c0 + lane : st_idx[d.st + (lane < r ? lane : 0)];
+    for (int q = 0; q < nrhs; ++q) {
+#pragma unroll 8
+        for (int t = 0; t < r; ++t) x[t * 64] = X[(long long) bcast_lane_i(myrow, t) * nrhs + q];
+        for (int t = r - 1; t >= 0; --t) {
+            double xt = x[t * 64];
+            if (t < w) { xt *= fast_rcp(L[((long long) t + (long long) t * r) * 64]); x[t * 64] = xt; }
+            const int top = min(t, w);                              // rows below w are the ancestors' (final) values
+            // M(i, t): U(i, t) = element (i, t); Cholesky: L(t, i) = element (t, i)
+            const double *Mt = (KIND == CS3_LU) ? L + (long long) t * r * 64 : L + (long long) t * 64;
+            const long long ms = (KIND == CS3_LU) ? 64 : (long long) r * 64;
+#pragma unroll 8
+            for (int i = 0; i < top; ++i) x[i * 64] -= Mt[i * ms] * xt;
+        }
+        if (live) {
+#pragma unroll 8
+            for (int t = 0; t < w; ++t) X[(long long) (d.c0 + t) * nrhs + q] = x[t * 64];
+        }
+    }
+}
+
 // ----------------------------------------------------------- permutations --
 // dst[k, :] = src[q[k], :]  (gather) or dst[q[k], :] = src[k, :] (scatter)
 __global__ void __launch_bounds__(256)
@@ -2058,15 +2391,15 @@ k_prologue(int *status, double *__restrict__ pool, long long big_begin, long lon
     }
 }
 
-// out[p] = map[p] < 0 ? 1.0 : vals[map[p]]
+// out[p] = map[p] < 0 ? 1.0 : value at the virtual pool offset map[p] of this matrix
 __global__ void __launch_bounds__(256)
-k_extract(const double *__restrict__ vals, const long long *__restrict__ map,
-          double *__restrict__ out, long long count)
+k_extract(const double *__restrict__ vals, const double *__restrict__ vals_il, long long il_len,
+          const long long *__restrict__ map, double *__restrict__ out, long long count)
 {
     for (long long p = (long long) blockIdx.x * blockDim.x + threadIdx.x; p < count;
          p += (long long) gridDim.x * blockDim.x) {
         const long long o = map[p];
-        out[p] = o < 0 ? 1.0 : vals[o];
+        out[p] = o < 0 ? 1.0 : (o < il_len ? vals_il[o * 64] : vals[o]);
     }
 }
 
@@ -2179,7 +2512,7 @@ static hipError_t launch_big_gather(const DeviceFactor &D, const LaunchGroup &g,
     const int chunks = (int) (g.max_asm >> 6);
     const int gx = std::max(1, std::min(64, (chunks + 4 * GATHER_UNROLL - 1) / (4 * GATHER_UNROLL)));
     hipLaunchKernelGGL(k_big_gather, dim3(gx, (unsigned) D.batch, g.count), dim3(256), 0, st, D.fdesc, g.first,
-                       D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool, D.nnz_a, D.pool_size);
+                       D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool_pm, D.nnz_a, D.pm_stride, IlView{D.pool_il, D.il_len});
     CS3_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -2195,7 +2528,7 @@ static hipError_t launch_big_block(const DeviceFactor &D, const LaunchGroup &g, 
     const int rem = g.max_r - std::min(start, g.max_r);        // largest trailing order over the group
     const int tiles = 1 + (rem + 63) / 64;
     hipLaunchKernelGGL((k_big_step<KIND>), dim3(tiles, tiles, g.count * batch), dim3(256), 0, st, D.fdesc,
-                       g.first, kb, D.pool, D.pool_size, D.dbuf, D.dbuf_size, inv_tol, D.status, (int) batch, D.tbuf);
+                       g.first, kb, D.pool_pm, D.pm_stride, D.dbuf, D.dbuf_size, inv_tol, D.status, (int) batch, D.tbuf);
     CS3_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -2218,8 +2551,15 @@ static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g
     const unsigned batch = (unsigned) D.batch;
     if (big_group_in_one_workgroup(KIND, D.batch, g)) {
         hipLaunchKernelGGL((k_front_wg<KIND>), dim3((unsigned) g.count, batch), dim3(512), wg_lds_bytes(KIND, g), st, D.fdesc,
-                           g.first, D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool, D.nnz_a, D.pool_size, inv_tol, D.status,
-                           wg_panel_ld(g), D.tbuf);
+                           g.first, D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool_pm, D.nnz_a, D.pm_stride,
+                           IlView{D.pool_il, D.il_len}, inv_tol, D.status, wg_panel_ld(g), D.tbuf);
+        CS3_LAUNCH_CHECK();
+        return hipSuccess;
+    }
+    if (g.cls == FC_IL) {
+        hipLaunchKernelGGL((k_front_il<KIND>), dim3((unsigned) g.count, (unsigned) D.ngroups), dim3(64), 0, st, D.fdesc, g.first,
+                           D.ila_pairs, D.ax, D.nnz_a, IlView{D.pool_il, D.il_len}, D.pool_pm, D.pm_stride, (int) D.batch,
+                           inv_tol, D.status);
         CS3_LAUNCH_CHECK();
         return hipSuccess;
     }
@@ -2232,7 +2572,7 @@ static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g
     dim3 grid((unsigned) g.count, batch);
     const size_t ld = (size_t) (g.max_r | 1);
     const size_t lds = (ld * (size_t) g.max_r + 4 * (size_t) g.max_r + 6) * sizeof(double);
-#define CS3_FRONT_ARGS D.fdesc, g.first, D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool, D.nnz_a, D.pool_size, inv_tol, D.status, D.tbuf
+#define CS3_FRONT_ARGS D.fdesc, g.first, D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool_pm, D.nnz_a, D.pm_stride, IlView{D.pool_il, D.il_len}, inv_tol, D.status, D.tbuf
     switch (g.cls) {
     case FC_R16:
     case FC_R32:      // only present when the analysis split the small fronts off (batched handles)
@@ -2391,13 +2731,13 @@ static hipError_t launch_fwd_big_chunk(const DeviceFactor &D, const LaunchGroup 
     const long long xs = D.n * (long long) nrhs, cvs = D.cv_size * (long long) nrhs;
     if (pl.wide)
         hipLaunchKernelGGL((k_fwd_big_step<KIND, BIG_CW>), dim3(pl.slices, pl.by, g.count), dim3(256), 0, st, D.sdesc,
-                           g.first, c * pl.cw, D.pool, D.cv, X, D.bigv, nrhs, D.pool_size, cvs, xs, D.bv_size);
+                           g.first, c * pl.cw, D.pool_pm, D.cv, X, D.bigv, nrhs, D.pm_stride, cvs, xs, D.bv_size);
     else if (pl.multi)
         hipLaunchKernelGGL((k_fwd_big_step_multi<KIND>), dim3(pl.slices, pl.by_multi, g.count), dim3(256), 0, st, D.sdesc,
-                           g.first, c * pl.cw, D.pool, D.cv, X, D.bigv, nrhs, D.pool_size, cvs, xs, D.bv_size);
+                           g.first, c * pl.cw, D.pool_pm, D.cv, X, D.bigv, nrhs, D.pm_stride, cvs, xs, D.bv_size);
     else
         hipLaunchKernelGGL((k_fwd_big_step<KIND, SOLVE_BW>), dim3(pl.slices, pl.by, g.count), dim3(256), 0, st, D.sdesc,
-                           g.first, c * pl.cw, D.pool, D.cv, X, D.bigv, nrhs, D.pool_size, cvs, xs, D.bv_size);
+                           g.first, c * pl.cw, D.pool_pm, D.cv, X, D.bigv, nrhs, D.pm_stride, cvs, xs, D.bv_size);
     CS3_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -2408,7 +2748,7 @@ static hipError_t launch_bwd_big_pre(const DeviceFactor &D, const LaunchGroup &g
     const BigSweepPlan pl = big_sweep_plan(D, g, nrhs);
     const size_t lds = (size_t) std::max(1, g.max_r) * sizeof(double);
     hipLaunchKernelGGL((k_bwd_big_init<KIND>), dim3(2, pl.by, g.count), dim3(256), lds, st, D.sdesc, g.first,
-                       D.st_idx, D.pool, X, D.bigv, nrhs, D.pool_size, D.n * (long long) nrhs, D.bv_size);
+                       D.st_idx, D.pool_pm, X, D.bigv, nrhs, D.pm_stride, D.n * (long long) nrhs, D.bv_size);
     CS3_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -2420,13 +2760,13 @@ static hipError_t launch_bwd_big_chunk(const DeviceFactor &D, const LaunchGroup 
     const long long xs = D.n * (long long) nrhs;
     if (pl.wide)
         hipLaunchKernelGGL((k_bwd_big_step<KIND, BIG_CW>), dim3(pl.slices, pl.by, g.count), dim3(256), 0, st, D.sdesc,
-                           g.first, c, D.pool, X, D.bigv, nrhs, D.pool_size, xs, D.bv_size);
+                           g.first, c, D.pool_pm, X, D.bigv, nrhs, D.pm_stride, xs, D.bv_size);
     else if (pl.multi)
         hipLaunchKernelGGL((k_bwd_big_step_multi<KIND>), dim3(pl.slices, pl.by_multi, g.count), dim3(256), 0, st, D.sdesc,
-                           g.first, c, D.pool, X, D.bigv, nrhs, D.pool_size, xs, D.bv_size);
+                           g.first, c, D.pool_pm, X, D.bigv, nrhs, D.pm_stride, xs, D.bv_size);
     else
         hipLaunchKernelGGL((k_bwd_big_step<KIND, SOLVE_BW>), dim3(pl.slices, pl.by, g.count), dim3(256), 0, st, D.sdesc,
-                           g.first, c, D.pool, X, D.bigv, nrhs, D.pool_size, xs, D.bv_size);
+                           g.first, c, D.pool_pm, X, D.bigv, nrhs, D.pm_stride, xs, D.bv_size);
     CS3_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -2439,11 +2779,11 @@ static void launch_rhs_sweep(const DeviceFactor &D, const LaunchGroup &g, double
     const long long xs = D.n * (long long) nrhs, cvs = D.cv_size * (long long) nrhs;
     dim3 grid((unsigned) g.count, (unsigned) D.batch, (unsigned) ((nrhs + 63) / 64));
     if (forward)
-        hipLaunchKernelGGL((k_fwd_rhs<KIND, RMAX>), grid, dim3(64), 0, st, D.sdesc, g.first, D.rl_pairs, D.pool, D.cv, X,
-                           nrhs, D.pool_size, cvs, xs);
+        hipLaunchKernelGGL((k_fwd_rhs<KIND, RMAX>), grid, dim3(64), 0, st, D.sdesc, g.first, D.rl_pairs, D.pool_pm, D.cv, X,
+                           nrhs, D.pm_stride, cvs, xs);
     else
-        hipLaunchKernelGGL((k_bwd_rhs<KIND, RMAX>), grid, dim3(64), 0, st, D.sdesc, g.first, D.st_idx, D.pool, X,
-                           nrhs, D.pool_size, xs);
+        hipLaunchKernelGGL((k_bwd_rhs<KIND, RMAX>), grid, dim3(64), 0, st, D.sdesc, g.first, D.st_idx, D.pool_pm, X,
+                           nrhs, D.pm_stride, xs);
 }
 
 template <int KIND>
@@ -2452,7 +2792,15 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
 {
     const long long xs = D.n * (long long) nrhs;
     const long long cvs = D.cv_size * (long long) nrhs;
-    if (g.cls == SK_SMALL && nrhs >= RHS_LANES_MIN) {
+    if (g.cls == SK_IL) {
+        dim3 grid((unsigned) g.count, (unsigned) D.ngroups);
+        if (forward)
+            hipLaunchKernelGGL((k_fwd_il<KIND, IL_RMAX>), grid, dim3(64), 0, st, D.sdesc, g.first, D.rl_pairs,
+                               IlView{D.pool_il, D.il_len}, D.cv, X, nrhs, cvs, xs, (int) D.batch);
+        else
+            hipLaunchKernelGGL((k_bwd_il<KIND, IL_RMAX>), grid, dim3(64), 0, st, D.sdesc, g.first, D.st_idx,
+                               IlView{D.pool_il, D.il_len}, X, nrhs, xs, (int) D.batch);
+    } else if (g.cls == SK_SMALL && nrhs >= RHS_LANES_MIN) {
         if (g.max_r <= 24) launch_rhs_sweep<KIND, 24>(D, g, X, nrhs, forward, st);
         else if (g.max_r <= 32) launch_rhs_sweep<KIND, 32>(D, g, X, nrhs, forward, st);
         else launch_rhs_sweep<KIND, 64>(D, g, X, nrhs, forward, st);
@@ -2461,19 +2809,19 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
             dim3 grid((unsigned) ((g.count + 3) / 4), (unsigned) D.batch, 1);
             if (forward)
                 hipLaunchKernelGGL((k_fwd_wave<KIND, 1>), grid, dim3(256), 0, st, D.sdesc, g.first, g.count, D.fasm_src,
-                                   D.fasm_tgt, D.flong_src, D.pool, D.cv, X, nrhs, D.pool_size, cvs, xs);
+                                   D.fasm_tgt, D.flong_src, D.pool_pm, D.cv, X, nrhs, D.pm_stride, cvs, xs);
             else
                 hipLaunchKernelGGL((k_bwd_wave<KIND, 1>), grid, dim3(256), 0, st, D.sdesc, g.first, g.count, D.st_idx,
-                                   D.pool, X, nrhs, D.pool_size, xs);
+                                   D.pool_pm, X, nrhs, D.pm_stride, xs);
         } else {
             constexpr int KT = 8;                   // right-hand sides per wave: the panel is read once per tile
             dim3 grid((unsigned) ((g.count + 3) / 4), (unsigned) D.batch, (unsigned) ((nrhs + KT - 1) / KT));
             if (forward)
                 hipLaunchKernelGGL((k_fwd_wave<KIND, KT>), grid, dim3(256), 0, st, D.sdesc, g.first, g.count, D.fasm_src,
-                                   D.fasm_tgt, D.flong_src, D.pool, D.cv, X, nrhs, D.pool_size, cvs, xs);
+                                   D.fasm_tgt, D.flong_src, D.pool_pm, D.cv, X, nrhs, D.pm_stride, cvs, xs);
             else
                 hipLaunchKernelGGL((k_bwd_wave<KIND, KT>), grid, dim3(256), 0, st, D.sdesc, g.first, g.count, D.st_idx,
-                                   D.pool, X, nrhs, D.pool_size, xs);
+                                   D.pool_pm, X, nrhs, D.pm_stride, xs);
         }
     } else if (g.cls == SK_BIG) {
         const BigSweepPlan pl = big_sweep_plan(D, g, nrhs);
@@ -2486,10 +2834,10 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
         const size_t lds = (size_t) (g.max_r + 1 + SOLVE_BW) * sizeof(double);
         if (forward)
             hipLaunchKernelGGL((k_fwd_blk<KIND>), grid, dim3(256), lds, st, D.sdesc, g.first, D.fasm_src,
-                               D.fasm_tgt, D.flong_src, D.pool, D.cv, X, nrhs, D.pool_size, cvs, xs);
+                               D.fasm_tgt, D.flong_src, D.pool_pm, D.cv, X, nrhs, D.pm_stride, cvs, xs);
         else
             hipLaunchKernelGGL((k_bwd_blk<KIND>), grid, dim3(256), lds, st, D.sdesc, g.first, D.st_idx,
-                               D.pool, X, nrhs, D.pool_size, xs);
+                               D.pool_pm, X, nrhs, D.pm_stride, xs);
     }
     CS3_LAUNCH_CHECK();
     return hipSuccess;
@@ -2681,8 +3029,8 @@ hipError_t launch_prologue(const DeviceFactor &D, const double *ax_src, const do
     const long long nzero = D.zero_big ? D.vals_size - D.big_begin : 0;     // k_front_wg zeroes its own buffer
     const long long nax = (ax_src && ax_src != D.ax) ? D.batch * D.nnz_a : 0;
     const long long total = nzero * D.batch + nax + (x_src ? D.n * (long long) nrhs * D.batch : 0);
-    hipLaunchKernelGGL(k_prologue, dim3(grid_for(std::max<long long>(total, 1), 256)), dim3(256), 0, st, D.status, D.pool,
-                       D.big_begin, nzero, D.pool_size, D.batch, ax_src, D.ax, nax, x_src, D.xp, D.q, D.n, nrhs);
+    hipLaunchKernelGGL(k_prologue, dim3(grid_for(std::max<long long>(total, 1), 256)), dim3(256), 0, st, D.status, D.pool_pm,
+                       D.big_begin, nzero, D.pm_stride, D.batch, ax_src, D.ax, nax, x_src, D.xp, D.q, D.n, nrhs);
     CS3_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -2697,10 +3045,11 @@ hipError_t launch_permute(const DeviceFactor &D, const double *src, double *dst,
     return hipSuccess;
 }
 
-hipError_t launch_extract(const double *vals, const long long *map, double *out, long long count, hipStream_t st)
+hipError_t launch_extract(const double *vals, const double *vals_il, long long il_len, const long long *map, double *out,
+                          long long count, hipStream_t st)
 {
     if (count == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_extract, dim3(grid_for(count, 256)), dim3(256), 0, st, vals, map, out, count);
+    hipLaunchKernelGGL(k_extract, dim3(grid_for(count, 256)), dim3(256), 0, st, vals, vals_il, il_len, map, out, count);
     CS3_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -109,13 +109,21 @@ double seconds_since(std::chrono::steady_clock::time_point t0)
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
-int front_class(i64 r, i64 w, bool split_small)
+i64 il_rmax()
 {
+    static const i64 v = [] { const char *e = std::getenv("CS3_IL_RMAX"); i64 x = e ? std::atoll(e) : IL_RMAX_DEFAULT; return std::min<i64>(std::max<i64>(x, 0), IL_RMAX); }();
+    return v;
+}
+
+int front_class(i64 r, i64 w, bool split_small, bool interleave)
+{
+    if (r <= il_rmax() && interleave) return FC_IL;   // batches of 64 or more: lane = matrix on the interleaved region
     if (r <= 32 && split_small) return FC_R32;   // batched handles: one wave per front, its own launch
     if (r <= 64) return FC_R64;       // one launch: k_front_mix (one wave for r <= 32, 16 x 16 threads above)
     // k_front_block: the image fits the LDS ((136*137 + 4*136 + 6) doubles = 153 KB of 160 KB) and the rows below
     // the first pivot block fit four stacked groups of 32
-    if (r <= 136 && r - std::min<i64>(w, 16) <= 128) return FC_LDS;
+    static const bool wg_all = std::getenv("CS3_WG_ALL") && std::getenv("CS3_WG_ALL")[0] == '1';
+    if (r <= 136 && r - std::min<i64>(w, 16) <= 128 && !(wg_all && split_small)) return FC_LDS;
     return FC_BIG;
 }
 
@@ -392,9 +400,21 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     auto order_r = [&](i32 s) -> i64 { return S.st_ptr[s + 1] - S.st_ptr[s]; };
     i64 voff = 0, cvoff = 0;
     S.max_front = 0; S.max_width = 0; S.flops = 0.0;
+    i64 il_min_batch = 64;
+    if (const char *e = std::getenv("CS3_IL_MIN_BATCH")) il_min_batch = std::atoll(e);
+    const bool interleave = S.batch >= il_min_batch;
+    for (i32 s = 0; s < ns; ++s) {                   // interleaved region first: dense r x r buffers of the FC_IL fronts
+        const i64 w = width(s), r = order_r(s);
+        if (front_class(r, w, S.batch >= 8, interleave) != FC_IL) continue;
+        S.lpan_off[s] = voff;
+        S.upan_off[s] = voff + w * r; S.u_sk[s] = 1; S.u_sj[s] = (i32) r;
+        S.cb_off[s] = voff + w + w * r; S.cb_ld[s] = (i32) r;
+        voff += r * r;
+    }
+    S.il_len = voff;
     for (i32 s = 0; s < ns; ++s) {                   // panels of the LDS-resident fronts
         const i64 w = width(s), r = order_r(s), nb = r - w;
-        S.sn_class[s] = front_class(r, w, S.batch >= 8);
+        S.sn_class[s] = front_class(r, w, S.batch >= 8, interleave);
         S.cv_off[s] = cvoff; cvoff += nb;
         S.rel_ptr[s + 1] = S.rel_ptr[s] + nb;
         S.max_front = std::max(S.max_front, r);
@@ -403,7 +423,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
             double m = (double) (r - k - 1);
             S.flops += (kind == CS3_LU) ? (m + 2.0 * m * m) : (m + m * (m + 1.0) + 1.0);
         }
-        if (S.sn_class[s] == FC_BIG) continue;
+        if (S.sn_class[s] == FC_BIG || S.sn_class[s] == FC_IL) continue;
         S.lpan_off[s] = voff; voff += r * w;
         // U panel w x nb, pivot rows contiguous: a wave whose lanes are rows stores and reads it coalesced
         if (kind == CS3_LU) { S.upan_off[s] = voff; voff += nb * w; S.u_sk[s] = 1; S.u_sj[s] = (i32) w; }
@@ -420,7 +440,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     S.vals_size = voff;
     i64 cboff = voff;
     for (i32 s = 0; s < ns; ++s) {                   // compact contribution blocks
-        if (S.sn_class[s] == FC_BIG) continue;
+        if (S.sn_class[s] == FC_BIG || S.sn_class[s] == FC_IL) continue;
         const i64 nb = order_r(s) - width(s);
         S.cb_off[s] = cboff; S.cb_ld[s] = (i32) nb;
         cboff += nb * nb;
@@ -468,6 +488,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     auto target_of = [&](i32 s, i64 ti, i64 tj) -> i32 {
         const i64 r = order_r(s);
         if (S.sn_class[s] == FC_BIG) return (i32) (S.lpan_off[s] + ti + tj * r);
+        if (S.sn_class[s] == FC_IL) return (i32) (ti + tj * r);          // front-local; the kernel adds the buffer's offset
         return (i32) (ti + tj * (r | 1));
     };
     struct Item { i32 tgt, src; };
@@ -521,6 +542,8 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     }
     S.asm_ptr.assign(ns + 1, 0);
     S.asm_src.clear(); S.asm_tgt.clear(); S.long_src.clear();
+    S.ila_ptr.assign(ns + 1, 0);
+    S.ila_pairs.clear();
     {
         std::vector<Item> items;
         for (i32 s = 0; s < ns; ++s) {
@@ -536,8 +559,25 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
                         items.push_back(Item{target_of(s, rel[ii], rel[jj]), (i32) (base + ii + jj * ldc)});
             }
             std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.tgt < b.tgt; });
-            emit_runs(items, S.asm_tgt, S.asm_src, S.long_src);
+            if (S.sn_class[s] == FC_IL) {
+                // lane = matrix assembly: (target, source) pairs in target order in which EVERY stored entry of the
+                // front appears (an entry without a source starts at zero), so each is written exactly once
+                const i64 r = order_r(s);
+                size_t a = 0;
+                for (i64 tj = 0; tj < r; ++tj)
+                    for (i64 ti = (kind == CS3_CHOLESKY ? tj : 0); ti < r; ++ti) {
+                        const i32 t = (i32) (ti + tj * r);
+                        if (a < items.size() && items[a].tgt < t) throw std::runtime_error("analyze: source outside the stored part of a front");
+                        if (a == items.size() || items[a].tgt != t) { S.ila_pairs.push_back(t); S.ila_pairs.push_back(IL_ZERO); }
+                        for (; a < items.size() && items[a].tgt == t; ++a) { S.ila_pairs.push_back(t); S.ila_pairs.push_back(items[a].src); }
+                    }
+                if (a != items.size()) throw std::runtime_error("analyze: source outside the stored part of a front");
+                while ((S.ila_pairs.size() / 2) % 16) { S.ila_pairs.push_back(-1); S.ila_pairs.push_back(IL_ZERO); }
+            } else {
+                emit_runs(items, S.asm_tgt, S.asm_src, S.long_src);
+            }
             S.asm_ptr[s + 1] = (i64) S.asm_tgt.size();
+            S.ila_ptr[s + 1] = (i64) (S.ila_pairs.size() / 2);
         }
     }
     if (S.asm_tgt.size() >= ((size_t) 1 << 31)) throw std::runtime_error("analyze: assembly list exceeds 32-bit offsets");
@@ -585,6 +625,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         }
     }
     auto solve_kind = [&](i32 s) {
+        if (S.sn_class[s] == FC_IL) return (int) SK_IL;
         if (order_r(s) <= 64) return (int) SK_SMALL;
         if (order_r(s) <= 128 && width(s) <= 64) return (int) SK_WAVE;
         // wide big fronts: one launch per chunk with many workgroups for a lone matrix; a batch fills the chip with one
@@ -602,7 +643,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     {
         std::vector<Item> items;
         for (i32 s = 0; s < ns; ++s) {
-            if (solve_kind(s) == SK_SMALL) {
+            if (solve_kind(s) == SK_SMALL || solve_kind(s) == SK_IL) {
                 items.clear();
                 for (i32 cp = S.child_ptr[s]; cp < S.child_ptr[s + 1]; ++cp) {
                     const i32 c = S.child_idx[cp];

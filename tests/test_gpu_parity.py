@@ -284,6 +284,67 @@ def test_batched_big_fronts_in_one_workgroup(gpu, orc, chol, nd):
             assert F.info.fail_col == n - 1
 
 
+@pytest.mark.parametrize("chol", [False, True])
+def test_interleaved_batches_lane_is_matrix(gpu, orc, chol):
+    """64 or more matrices: fronts of order <= 32 live matrix-interleaved and run lane = matrix (k_front_il, k_fwd_il,
+    k_bwd_il); larger fronts read their children's contribution blocks from the interleaved block.  130 matrices =
+    two full groups and a partial one.  Every checked matrix equals the oracle (pattern bit-exact, values 1e-10) and the
+    same matrix factorised alone; several right-hand sides go through the same kernels."""
+    m, n, Ap, Ai, Ax = synth.grid_jacobian(n=3000, seed=13)
+    kind = gpu.CS3_LU
+    if chol:
+        ei, ej = synth.spd_grid_pattern(3000, seed=21)
+        m, n, Ap, Ai, Ax = synth.spd_grid_matrix(3000, ei, ej, seed=22)
+        kind = gpu.CS3_CHOLESKY
+    nb = 130
+    rng = np.random.default_rng(130 + chol)
+    scale = 1.0 + rng.uniform(0.0, 1.0, size=(nb, 1))
+    AX = Ax[None, :] * scale
+    if not chol:
+        AX = AX * (1.0 + 0.01 * rng.uniform(-1.0, 1.0, size=AX.shape))         # stays diagonally dominant
+    B = rng.standard_normal((nb, n, 3))
+    tol = 0.0 if chol else 1e-3
+    with gpu.Factorization(m, n, Ap, Ai, kind=kind, batch=nb) as F:
+        F.factor(AX, tol)
+        X = F.solve(B)
+        x1 = F.solve(np.ascontiguousarray(B[:, :, :1]))
+        Y = F.usolve(F.lsolve(B))
+        q = F.ordering()["q"]
+        facs = {i: F.factors(b=i) for i in (0, 63, 64, 127, 128, 129)}
+        F.factor(AX, tol)
+        assert np.array_equal(F.solve(B), X)                                     # run-to-run bitwise
+    assert rel_err(x1[:, :, 0], X[:, :, 0]) <= 1e-13
+    for i, (Lp, Li, Lx, Up, Ui, Ux) in facs.items():
+        if chol:
+            assert_factor_equal(n, (Lp, Li, Lx), _oracle_chol(orc, n, Ap, Ai, AX[i], q), "interleaved chol %d" % i)
+        else:
+            oL = orc.csc_lu_f(n, n, Ap, Ai, AX[i], q, 1e-3)
+            assert np.array_equal(oL[6], np.argsort(q).astype(np.int32))
+            assert_factor_equal(n, (Lp, Li, Lx), oL[0:3], "interleaved L %d" % i)
+            assert_factor_equal(n, (Up, Ui, Ux), oL[3:6], "interleaved U %d" % i)
+    for i in range(nb):
+        A = csc_to_scipy(m, n, Ap, Ai, AX[i])
+        bound = 1e-12 * (abs(A).sum(axis=0).max() * np.abs(X[i]).max() + np.abs(B[i]).max())
+        assert np.abs(A @ X[i] - B[i]).max() <= bound, i
+    with gpu.Factorization(m, n, Ap, Ai, kind=kind) as G:
+        G.factor(AX[64], tol)
+        assert rel_err(X[64], G.solve(B[64])) <= 1e-12
+        assert rel_err(Y[64], G.usolve(G.lsolve(B[64]))) <= 1e-12                # the sweeps alone, in pivot order
+    # a bad pivot in ONE matrix of a group is reported (here inside an interleaved leaf front)
+    rows = Ai[:Ap[n]]; cols = np.repeat(np.arange(n), np.diff(Ap))
+    bad = AX.copy()
+    first = q[0]
+    bad[77, (rows == cols) & (cols == first)] = 0.0 if not chol else -1.0
+    with gpu.Factorization(m, n, Ap, Ai, kind=kind, batch=nb) as F:
+        with pytest.raises(gpu.NotPositiveDefinite if chol else gpu.SingularMatrix):
+            F.factor(bad, tol)
+        assert F.info.fail_col == 0
+        with pytest.raises(gpu.Cs3Error):
+            import torch
+            buf = torch.empty(8, dtype=torch.float64, device="cuda")
+            F.export_factor_dev(buf.data_ptr())                                  # not offered for interleaved batches
+
+
 # ------------------------------------------- full-size, size-independent ----
 
 def test_config3_full_size_properties(gpu):

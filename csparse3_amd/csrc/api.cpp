@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <utility>
 #include <stdexcept>
 #include <string>
 
@@ -41,11 +42,13 @@ struct cs3_handle_s {
     hipGraphExec_t factor_graph = nullptr;
     double factor_graph_inv_tol = 0.0;
     std::map<int, hipGraphExec_t> solve_graphs;   // keyed by nrhs
+    std::map<std::pair<int, const void *>, hipGraphExec_t> solve_graphs_px;   // fused permutations: keyed by (nrhs, caller's X)
     std::map<int, hipGraphExec_t> fused_graphs;   // factor + overlapped forward + backward, keyed by nrhs
     double fused_inv_tol = 0.0;
     i64 *d_lmap = nullptr, *d_umap = nullptr;
     double *d_lx = nullptr, *d_ux = nullptr;
     long long fail_col = -1;
+    bool inverses_valid = false;      // inverted diagonal blocks (many-RHS GEMM sweeps) match the current factors
 };
 
 namespace {
@@ -63,6 +66,8 @@ void drop_solve_graphs(cs3_handle h)
 {
     for (auto &kv : h->solve_graphs) (void) hipGraphExecDestroy(kv.second);
     h->solve_graphs.clear();
+    for (auto &kv : h->solve_graphs_px) (void) hipGraphExecDestroy(kv.second);
+    h->solve_graphs_px.clear();
     for (auto &kv : h->fused_graphs) (void) hipGraphExecDestroy(kv.second);
     h->fused_graphs.clear();
 }
@@ -77,7 +82,8 @@ void release_device(cs3_handle h)
     h->fj.destroy();
     void **ptrs[] = {(void **) &D.fdesc, (void **) &D.st_idx, (void **) &D.asm_src, (void **) &D.asm_tgt, (void **) &D.long_src,
                      (void **) &D.sdesc, (void **) &D.fasm_src, (void **) &D.fasm_tgt, (void **) &D.flong_src, (void **) &D.rl_pairs,
-                     (void **) &D.q, (void **) &D.ila_pairs, (void **) &D.ax, (void **) &D.pool, (void **) &D.dbuf, (void **) &D.tbuf, (void **) &D.bigv,
+                     (void **) &D.q, (void **) &D.ila_pairs, (void **) &D.inv_tasks, (void **) &D.dinv, (void **) &D.gv,
+                     (void **) &D.ax, (void **) &D.pool, (void **) &D.dbuf, (void **) &D.tbuf, (void **) &D.bigv,
                      (void **) &D.cv, (void **) &D.xp, (void **) &D.status, (void **) &h->d_lmap, (void **) &h->d_umap,
                      (void **) &h->d_lx, (void **) &h->d_ux};
     for (void **p : ptrs) if (*p) { (void) hipFree(*p); *p = nullptr; }
@@ -110,6 +116,8 @@ int ensure_device_impl(cs3_handle h)
     D.kind = S.kind; D.n = S.n; D.nnz_a = S.nnzA; D.batch = h->batch;
     D.vals_size = S.vals_size; D.pool_size = S.pool_size; D.cv_size = S.cv_size; D.big_begin = S.big_begin;
     D.bv_size = S.bv_size;
+    D.gv_size = S.gv_size; D.dinv_size = S.dinv_size; D.n_inv_tasks = (int) (S.inv_tasks.size() / 2);
+    D.inv_tasks_host.assign(S.inv_tasks.begin(), S.inv_tasks.end());
     D.zero_big = false;
     for (const LaunchGroup &g : S.groups)
         if (g.cls == FC_BIG && !big_group_in_one_workgroup(S.kind, h->batch, g)) D.zero_big = true;
@@ -137,6 +145,7 @@ int ensure_device_impl(cs3_handle h)
         f.lpan = S.lpan_off[s]; f.upan = S.upan_off[s]; f.cv = S.cv_off[s]; f.st = S.st_ptr[s];
         f.fasm_begin = S.fasm_ptr[s]; f.fasm_count = (int) (S.fasm_ptr[s + 1] - S.fasm_ptr[s]);
         f.bv = S.bv_off[s];
+        f.gv = S.gv_off[s]; f.dinv = S.dinv_off[s];
         f.rl_begin = S.rl_ptr[s]; f.rl_count = (int) (S.rl_ptr[s + 1] - S.rl_ptr[s]);
         f.c0 = S.sn_ptr[s];
         f.r = (int) (S.st_ptr[s + 1] - S.st_ptr[s]);
@@ -157,6 +166,8 @@ int ensure_device_impl(cs3_handle h)
     if ((rc = upload(&D.long_src, S.long_src))) return rc;
     if ((rc = upload(&D.q, S.q))) return rc;
     if ((rc = upload(&D.ila_pairs, S.ila_pairs))) return rc;
+    if ((rc = upload(&D.inv_tasks, S.inv_tasks))) return rc;
+    CS3_HIP(hipMalloc((void **) &D.dinv, std::max<size_t>(1, (size_t) (D.batch * D.dinv_size)) * sizeof(double)));
     D.il_len = S.il_len;
     D.pm_stride = S.pool_size - S.il_len;
     D.ngroups = (D.batch + 63) / 64;
@@ -191,11 +202,13 @@ int ensure_rhs_capacity(cs3_handle h, long long nrhs)
     if (D.cv) (void) hipFree(D.cv);
     if (D.xp) (void) hipFree(D.xp);
     if (D.bigv) (void) hipFree(D.bigv);
-    D.cv = D.xp = D.bigv = nullptr;
+    if (D.gv) (void) hipFree(D.gv);
+    D.cv = D.xp = D.bigv = D.gv = nullptr;
     D.nrhs_cap = 0;                           // nothing usable until all three are back
     CS3_HIP(hipMalloc((void **) &D.cv, std::max<size_t>(1, (size_t) (D.batch * D.cv_size * nrhs)) * sizeof(double)));
     CS3_HIP(hipMalloc((void **) &D.xp, std::max<size_t>(1, (size_t) (D.batch * D.n * nrhs)) * sizeof(double)));
     CS3_HIP(hipMalloc((void **) &D.bigv, std::max<size_t>(1, (size_t) (D.batch * D.bv_size * nrhs)) * sizeof(double)));
+    CS3_HIP(hipMalloc((void **) &D.gv, std::max<size_t>(1, (size_t) (D.batch * D.gv_size * nrhs)) * sizeof(double)));
     D.nrhs_cap = nrhs;
     return CS3_OK;
 }
@@ -238,6 +251,7 @@ int run_factor(cs3_handle h, const double *ax_dev, double tol, hipStream_t st)
         CS3_HIP(launch_factor_levels(D, h->S.groups, inv_tol, st, h->fj));
     }
     h->factored = true;
+    h->inverses_valid = false;
     return CS3_OK;
 }
 
@@ -267,7 +281,41 @@ int run_solve(cs3_handle h, double *x_dev, long long k, int mode, hipStream_t st
     if (rc) return rc;
     DeviceFactor &D = h->D;
     const int nrhs = (int) k;
-    if (mode == 0) {
+    D.inverses_in_sweep = false;
+    if (nrhs >= 16 && D.n_inv_tasks > 0 && !h->inverses_valid) {      // many right-hand sides: GEMM sweeps need the inverted blocks
+        CS3_HIP(launch_diag_inverses(D, st));
+        h->inverses_valid = true;
+    }
+    D.xm = XMap();
+    if (mode == 0 && permutation_can_fuse(D, nrhs)) {
+        // the permutations ride on the sweeps: the forward sweep reads row q[k] of the caller's X, the backward sweep
+        // writes the solution rows back there; X's address is baked into the graph, so graphs are kept per (nrhs, X)
+        D.xm.src = x_dev; D.xm.dst = x_dev; D.xm.q = D.q;
+        if (h->use_graph) {
+            const auto key = std::make_pair(nrhs, (const void *) x_dev);
+            auto it = h->solve_graphs_px.find(key);
+            if (it == h->solve_graphs_px.end()) {
+                if (h->solve_graphs_px.size() >= 8) {           // callers that rotate buffers: bounded cache
+                    CS3_HIP(hipStreamSynchronize(st));
+                    for (auto &kv : h->solve_graphs_px) (void) hipGraphExecDestroy(kv.second);
+                    h->solve_graphs_px.clear();
+                }
+                hipGraphExec_t exec = nullptr;
+                rc = capture(h, &exec, [&](hipStream_t cs) {
+                    hipError_t e = launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, true, cs, h->fj);
+                    if (e != hipSuccess) return e;
+                    return launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, false, cs, h->fj);
+                });
+                if (rc) { D.xm = XMap(); return rc; }
+                it = h->solve_graphs_px.emplace(key, exec).first;
+            }
+            CS3_HIP(hipGraphLaunch(it->second, st));
+        } else {
+            CS3_HIP(launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, true, st, h->fj));
+            CS3_HIP(launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, false, st, h->fj));
+        }
+        D.xm = XMap();
+    } else if (mode == 0) {
         CS3_HIP(launch_permute(D, x_dev, D.xp, nrhs, false, st));
         if (h->use_graph) {
             auto it = h->solve_graphs.find(nrhs);
@@ -302,6 +350,7 @@ int run_factor_solve(cs3_handle h, const double *ax_dev, const double *b_dev, do
     DeviceFactor &D = h->D;
     const int nrhs = (int) k;
     const double inv_tol = (tol > 0.0) ? 1.0 / tol : HUGE_VAL;
+    D.inverses_in_sweep = true;                                // captured with the graph: the forward sweep inverts group by group
     CS3_HIP(launch_prologue(D, ax_dev, b_dev, nrhs, st));      // right-hand sides are read from b_dev, the solution goes to x_dev
     if (h->use_graph) {
         if (h->fused_inv_tol != inv_tol) {
@@ -326,7 +375,9 @@ int run_factor_solve(cs3_handle h, const double *ax_dev, const double *b_dev, do
         CS3_HIP(launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, false, st, h->fj));
     }
     CS3_HIP(launch_permute(D, D.xp, x_dev, nrhs, true, st));
+    D.inverses_in_sweep = false;
     h->factored = true;
+    h->inverses_valid = nrhs >= 16;                            // a many-RHS fused call leaves them current
     return CS3_OK;
 }
 
@@ -604,6 +655,7 @@ int cs3_import_factor_dev(cs3_handle h, const double *src_dev, void *stream)
                                  (size_t) D.vals_size * sizeof(double), (size_t) D.vals_size * sizeof(double),
                                  (size_t) D.batch, hipMemcpyDeviceToDevice, (hipStream_t) stream));
     h->factored = true;
+    h->inverses_valid = false;
     h->fail_col = -1;
     return CS3_OK;
 }

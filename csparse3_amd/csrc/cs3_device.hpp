@@ -24,10 +24,19 @@ struct FrontDesc {
 // 32-row columns of a panel whatever its height.
 constexpr size_t POOL_SLACK = 2048;
 
+// Fused permutations (many right-hand sides): the forward sweep takes row k of the permuted right-hand sides from
+// src[q[k]], the backward sweep writes solution row k to dst[q[k]] as well; null pointers = off (X holds pivot order).
+struct XMap {
+    const double *src = nullptr;
+    double *dst = nullptr;
+    const int *q = nullptr;
+};
+
 // What the solve kernels read per front, in SOLVE-schedule order.
 struct SolveDesc {
     long long lpan, upan, cv, st, fasm_begin;
     long long bv;                 // SK_BIG fronts: offset of the full front vector in bigv
+    long long gv, dinv;           // fronts of order > 64: first row in the gv buffer, offset of the inverted diagonal blocks
     long long rl_begin;           // SK_SMALL fronts: first (target, source) pair of the children's additions
     int rl_count;                 //   pairs, a multiple of 16
     int fasm_count;
@@ -64,6 +73,14 @@ struct DeviceFactor {
     double *xp = nullptr;         // [batch][n * nrhs_cap] right-hand sides in pivot order
     double *bigv = nullptr;       // [batch][nrhs_cap][bv_size] front vectors of the wide big fronts
     long long bv_size = 0;
+    double *gv = nullptr;         // [batch][gv_size][nrhs_cap] front vectors of the GEMM sweeps, row-major [row][rhs]
+    double *dinv = nullptr;       // [batch][dinv_size] inverted 64 x 64 diagonal blocks of the fronts of order > 64
+    long long gv_size = 0, dinv_size = 0;
+    int *inv_tasks = nullptr;     // (position in the solve schedule, chunk) pairs
+    int n_inv_tasks = 0;
+    std::vector<int> inv_tasks_host;
+    bool inverses_in_sweep = false;   // the forward sweep computes them group by group (fused factor + solve graph)
+    XMap xm;                          // what the sweeps captured / launched next should use (set by the caller)
     long long nrhs_cap = 0;
     int *status = nullptr;        // [1] first failing pivot column, 0x7f7f7f7f when clean
     long long *tbuf = nullptr;    // diagnostics (CS3_PROFILE=1): 8 shader-clock stamps per front, schedule order
@@ -90,6 +107,8 @@ struct ForkJoin {
 };
 
 hipError_t prepare_kernels();
+hipError_t launch_diag_inverses(const DeviceFactor &D, hipStream_t st);
+bool permutation_can_fuse(const DeviceFactor &D, int nrhs);   // once after a factorisation, before a many-RHS sweep
 bool big_group_in_one_workgroup(int kind, long long batch, const LaunchGroup &g);
 hipError_t launch_factor_levels(const DeviceFactor &D, const std::vector<LaunchGroup> &groups,
                                 double inv_tol, hipStream_t st, ForkJoin &fj);

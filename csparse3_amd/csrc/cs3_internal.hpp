@@ -51,6 +51,7 @@ struct LaunchGroup {          // fronts of one level that share a kernel configu
     i32 max_r;                // largest front order in the group (sizes dynamic LDS)
     i32 max_w;                // widest supernode in the group (block steps of the big path)
     i64 max_asm;              // longest assembly list in the group
+    i32 n16 = 0;              // solve groups: leading fronts of order <= 16 (sorted first: a leaner kernel instance takes them)
 };
 
 struct Symbolic {
@@ -106,6 +107,13 @@ struct Symbolic {
     std::vector<i32> rl_pairs;                //   sorted by target, padded to multiples of 16 with target -1
     std::vector<i64> bv_off;                  // kind-2 fronts: offset of their full front vector in the bigv buffer
     i64 bv_size = 0;
+    // Many right-hand sides: fronts of order > 64 sweep as GEMMs (k_gemm_fwd / k_gemm_bwd).  Their front vectors
+    // live row-major [row][rhs] in the gv buffer (gv_off, gv_size rows); the inverses of their 64 x 64 diagonal
+    // blocks (L then U, 2 * 4096 doubles per chunk of 64 pivots) in the dinv buffer (dinv_off, dinv_size doubles);
+    // inv_tasks lists (position in the solve schedule, chunk) for the kernel that computes them.
+    std::vector<i64> gv_off, dinv_off;
+    i64 gv_size = 0, dinv_size = 0;
+    std::vector<i32> inv_tasks;
     std::vector<LaunchGroup> sgroups;
     // schedule
     i32 nlevels = 0;

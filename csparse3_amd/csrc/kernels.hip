@@ -1308,11 +1308,14 @@ template <int KIND, int RMAX>
 __global__ void __launch_bounds__(64, (RMAX <= 32) ? 2 : 1)
 k_fwd_rhs(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ rl,
           const double *__restrict__ pool_all, double *cv_all, double *X_all,
-          int nrhs, long long pool_stride, long long cv_stride, long long x_stride)
+          int nrhs, long long pool_stride, long long cv_stride, long long x_stride, XMap xm)
 {
     __shared__ double vl[RMAX * 64];
     const SolveDesc d = sd[first + blockIdx.x];
     const int lane = threadIdx.x;
+    // fused permutation: row k of the right-hand sides in pivot order is row q[k] of the caller's array
+    const double *Xin = xm.src ? xm.src + (long long) blockIdx.y * x_stride : X_all + (long long) blockIdx.y * x_stride;
+    const int qrow = xm.src ? xm.q[d.c0 + (lane < d.w ? lane : 0)] : d.c0 + lane;
     const int col = blockIdx.z * 64 + lane;
     const bool live = col < nrhs;
     const long long lo = live ? col : 0;
@@ -1336,7 +1339,7 @@ k_fwd_rhs(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ r
 #pragma unroll
     for (int t = 0; t < RMAX; ++t) {
         double x0 = 0.0;
-        if (t < w) x0 = X[(long long) (d.c0 + t) * nrhs + lo];
+        if (t < w) x0 = Xin[(long long) bcast_lane_i(qrow, t) * nrhs + lo];
         vl[t * 64 + lane] = x0;
     }
     // what the children add, sorted by target: sum a run in a register, add it once
@@ -1408,7 +1411,7 @@ template <int KIND, int RMAX>
 __global__ void __launch_bounds__(64, (RMAX <= 32) ? 2 : 1)
 k_bwd_rhs(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ st_idx,
           const double *__restrict__ pool_all, double *X_all,
-          int nrhs, long long pool_stride, long long x_stride)
+          int nrhs, long long pool_stride, long long x_stride, XMap xm)
 {
     const SolveDesc d = sd[first + blockIdx.x];
     const int lane = threadIdx.x;
@@ -1451,15 +1454,25 @@ k_bwd_rhs(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ s
             for (int i0 = 0; i0 < t; i0 += 8) {
                 if (i0 < w) {
 #pragma unroll
-                    for (int i = i0; i < i0 + 8 && i < t; ++i) x[i] -= M.at(i, t) * x[t];
+                    for (int i = i0; i < i0 + 8; ++i)
+                        if (i < t) x[i] -= M.at(i, t) * x[t];
                 }
             }
         }
     }
+    // fused permutation: the solution row also goes home, to row q[k] of the caller's array.  The row map is read by ALL
+    // lanes before the dead ones leave: it is fetched lane-to-scalar below, also from lanes beyond the last right-hand side
+    const int qrow = xm.dst ? xm.q[d.c0 + (lane < w ? lane : 0)] : 0;
     if (!live) return;
 #pragma unroll
     for (int t = 0; t < RMAX; ++t)
         if (t < w) X[(long long) (d.c0 + t) * nrhs + col] = x[t];
+    if (xm.dst) {
+        double *Xo = xm.dst + (long long) blockIdx.y * x_stride;
+#pragma unroll
+        for (int t = 0; t < RMAX; ++t)
+            if (t < w) Xo[(long long) bcast_lane_i(qrow, t) * nrhs + col] = x[t];
+    }
 }
 
 // One workgroup per front (any size): the front vector lives in LDS, the pivot
@@ -2347,6 +2360,336 @@ k_bwd_il(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ st
     }
 }
 
+// ---------------------------------------- many right-hand sides: GEMM sweeps --
+// With 16 or more right-hand sides the fronts of order > 64 (the top of the tree, the dense root) sweep as
+// GEMMs on the matrix cores instead of 64-step substitutions: the 64 x 64 diagonal blocks of L and U are inverted
+// once per sweep (k_inv_diag, one workgroup per block, all in one launch), and a chunk of 64 pivots then costs two
+// 64 x 64 x 64 products per workgroup and tile of 64 right-hand sides,
+//      Y = Linv_cc V_c      and      V_rows -= L(rows, chunk) Y         (backward: Uinv_cc, U(rows, chunk)),
+// on v_mfma_f64_16x16x4 with both operands staged in LDS.  The front vector is row-major [row][rhs] (gv buffer),
+// like X and the contribution vectors, so every global access of a tile is 512 contiguous bytes per row.
+// A chunk step is still one launch (chunk c + 1 needs what chunk c did to the rows below it), but takes a few
+// microseconds instead of the 15 to 35 of the substitution kernels, and fronts with up to 64 pivots need one.
+// Every workgroup recomputes Y for its tile (cheap) rather than wait for another one.
+constexpr int GC = 64;                         // pivots per chunk
+constexpr int GLD = 80;                        // LDS row stride of the 64 x 64 operand tiles: 80 = 16 mod 32 doubles, so the
+                                               //   two 16-lane rows of a half-wave's ds_read_b64 fall on disjoint banks
+constexpr size_t GEMM_LDS = 2 * (size_t) GC * GLD * sizeof(double);     // 80 KB: two workgroups per CU
+
+template <int KIND>
+__global__ void __launch_bounds__(256)
+k_inv_diag(const SolveDesc *__restrict__ sd, const int *__restrict__ tasks, int task0,
+           const double *__restrict__ pool_all, long long pool_stride, double *__restrict__ dinv_all, long long dinv_stride)
+{
+    const int t = tasks[2 * (task0 + blockIdx.x)], c = tasks[2 * (task0 + blockIdx.x) + 1];
+    const SolveDesc d = sd[t];
+    const double *L = pool_all + (long long) blockIdx.y * pool_stride + d.lpan;
+    double *out = dinv_all + (long long) blockIdx.y * dinv_stride + d.dinv + (long long) c * 2 * GC * GC;
+    const int r = d.r, w = d.w, kb = c * GC, bw = min(GC, w - kb);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int QW = 16;                      // identity columns per wave
+    {   // Linv: L x = e_j, lane = row; column j of the inverse goes to out[j * 64 + row], zero outside bw x bw
+        BlockTriangle<KIND, true> ta;
+        ta.load(L, r, kb, bw);
+        double vi[QW];
+#pragma unroll
+        for (int q = 0; q < QW; ++q) vi[q] = (lane == QW * wv + q && lane < bw) ? 1.0 : 0.0;
+        ta.template solve_multi<QW>(vi, bw);
+#pragma unroll
+        for (int q = 0; q < QW; ++q) out[(QW * wv + q) * GC + lane] = (lane < bw && QW * wv + q < bw) ? vi[q] : 0.0;
+    }
+    {   // Uinv (Cholesky: the inverse of L')
+        BlockTriangle<KIND, false> tb;
+        tb.load(L, r, kb, bw);
+        double vi[QW];
+#pragma unroll
+        for (int q = 0; q < QW; ++q) vi[q] = (lane == QW * wv + q && lane < bw) ? 1.0 : 0.0;
+        tb.template solve_multi<QW>(vi, bw);
+#pragma unroll
+        for (int q = 0; q < QW; ++q) out[GC * GC + (QW * wv + q) * GC + lane] = (lane < bw && QW * wv + q < bw) ? vi[q] : 0.0;
+    }
+}
+
+// Front vector of the GEMM fronts from the gather lists (as k_fwd_big_gather), written row-major [row][rhs].
+__global__ void __launch_bounds__(256)
+k_gemm_gather(const SolveDesc *__restrict__ sd, int first,
+              const int *__restrict__ fsrc, const int *__restrict__ ftgt, const int *__restrict__ flong,
+              const double *__restrict__ cv_all, const double *__restrict__ X_all, double *__restrict__ gv_all,
+              int nrhs, long long cv_stride, long long x_stride, long long gv_stride, XMap xm)
+{
+    const SolveDesc d = sd[first + blockIdx.z];
+    const int b = blockIdx.y / nrhs, rhs = blockIdx.y % nrhs;
+    const double *cv = cv_all + (long long) b * cv_stride;
+    const double *X = (xm.src ? xm.src : X_all) + (long long) b * x_stride;
+    const int *qm = xm.src ? xm.q : nullptr;
+    double *v = gv_all + (long long) b * gv_stride + d.gv * (long long) nrhs + rhs;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    gather_front(d.fasm_begin, d.fasm_count >> 6, wave * GATHER_UNROLL, gridDim.x * 4 * GATHER_UNROLL, fsrc, ftgt, flong,
+                 [&](int q) -> const double * {
+                     if (q >= 0) return cv + (long long) q * nrhs + rhs;
+                     const int row = qm ? qm[~q] : ~q;
+                     return X + (long long) row * nrhs + rhs;
+                 },
+                 [&](int t, double val) { v[(long long) t * nrhs] = val; });
+}
+
+// 64 x 64 x 64 product on the matrix cores, operands in LDS: acc(i, n) += sgn * A(i, k) B(k, n), with
+// A at As[k * GLD + i], B at Bs[k * GLD + n]; wave wv owns rows 16 wv .. 16 wv + 15, acc[nt][v] = entry
+// (16 wv + mq + 4 v, 16 nt + mi) in the register layout of v_mfma_f64_16x16x4.
+template <bool NEG>
+__device__ __forceinline__ void gemm64(const double *As, const double *Bs, double4_t (&acc)[4], int wv, int mi, int mq)
+{
+#pragma unroll
+    for (int k0 = 0; k0 < GC; k0 += 4) {
+        const double a0 = As[(k0 + mq) * GLD + 16 * wv + mi];
+        const double a = NEG ? -a0 : a0;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+            acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[(k0 + mq) * GLD + 16 * nt + mi], acc[nt], 0, 0, 0);
+    }
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256)
+k_gemm_fwd(const SolveDesc *__restrict__ sd, int first, int c,
+           const double *__restrict__ pool_all, const double *__restrict__ dinv_all, double *__restrict__ cv_all,
+           double *__restrict__ X_all, double *__restrict__ gv_all, int nrhs, long long pool_stride, long long dinv_stride,
+           long long cv_stride, long long x_stride, long long gv_stride, int batch)
+{
+    extern __shared__ __attribute__((aligned(16))) double gsm[];
+    double *As = gsm, *Bs = gsm + GC * GLD;
+    const SolveDesc d = sd[first + blockIdx.z / batch];
+    const int b = blockIdx.z % batch;
+    const int r = d.r, w = d.w;
+    if (c * GC >= w) return;
+    const int kb = c * GC, bw = min(GC, w - kb), ke = kb + bw;
+    const int nsl = (r - ke + GC - 1) / GC;
+    if ((int) blockIdx.x > 0 && (int) blockIdx.x >= nsl) return;
+    const int n0 = blockIdx.y * GC, nlive = min(GC, nrhs - n0);
+    const double *L = pool_all + (long long) b * pool_stride + d.lpan;
+    const double *Linv = dinv_all + (long long) b * dinv_stride + d.dinv + (long long) c * 2 * GC * GC;
+    double *V = gv_all + (long long) b * gv_stride + d.gv * (long long) nrhs;                 // V[row * nrhs + rhs]
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, mi = lane & 15, mq = lane >> 4;
+    // every global load of the workgroup goes out first (one round trip): the inverse, the chunk's rows of V, my
+    // slice of the panel and my rows of V
+    const bool has_rows = nsl > 0;
+    const int row0 = ke + blockIdx.x * GC;
+    double ra[16], rb[16], rl[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = tid + 256 * q, k = e >> 6, i = e & 63;
+        ra[q] = Linv[e];
+        rb[q] = load_if(V, (long long) (kb + k) * nrhs + n0 + i, k < bw && i < nlive);
+        rl[q] = load_if(L, (long long) (row0 + i) + (long long) (kb + k) * r, has_rows && row0 + i < r && k < bw);
+    }
+    double4_t acc2[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int row = row0 + 16 * wv + mq + 4 * v, n = 16 * nt + mi;
+            acc2[nt][v] = load_if(V, (long long) row * nrhs + n0 + n, has_rows && row < r && n < nlive);
+        }
+    // ---- Y = Linv_cc V_c
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = tid + 256 * q, k = e >> 6, i = e & 63;
+        As[k * GLD + i] = ra[q];
+        Bs[k * GLD + i] = rb[q];
+    }
+    __syncthreads();
+    double4_t acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = double4_t{0.0, 0.0, 0.0, 0.0};
+    gemm64<false>(As, Bs, acc, wv, mi, mq);
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Bs[(16 * wv + mq + 4 * v) * GLD + 16 * nt + mi] = acc[nt][v];     // Y(k, n)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = tid + 256 * q, k = e >> 6, i = e & 63;
+        As[k * GLD + i] = rl[q];                                                                     // L(row0 + i, kb + k)
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        double *X = X_all + (long long) b * x_stride;
+        for (int e = tid; e < GC * GC; e += 256) {
+            const int k = e >> 6, n = e & 63;
+            if (k < bw && n < nlive) X[(long long) (d.c0 + kb + k) * nrhs + n0 + n] = Bs[k * GLD + n];
+        }
+    }
+    if (!has_rows) return;
+    // ---- my 64 rows below the chunk:  V_rows -= L(rows, chunk) Y
+    gemm64<true>(As, Bs, acc2, wv, mi, mq);
+    const bool last = ke >= w && d.parent >= 0;             // rows below the pivots are final: the parent's input
+    double *cv = cv_all + (long long) b * cv_stride;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int row = row0 + 16 * wv + mq + 4 * v, n = 16 * nt + mi;
+            if (row < r && n < nlive) {
+                V[(long long) row * nrhs + n0 + n] = acc2[nt][v];
+                if (last) cv[(d.cv + row - w) * nrhs + n0 + n] = acc2[nt][v];
+            }
+        }
+}
+
+// V(pivot rows) = X(pivot rows) - U12 X(ancestors' rows): one workgroup per 64 pivot rows and tile of 64 right-hand sides
+template <int KIND>
+__global__ void __launch_bounds__(256)
+k_gemm_bwd_init(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ st_idx,
+                const double *__restrict__ pool_all, const double *__restrict__ X_all, double *__restrict__ gv_all,
+                int nrhs, long long pool_stride, long long x_stride, long long gv_stride, int batch)
+{
+    extern __shared__ __attribute__((aligned(16))) double gsm[];
+    double *As = gsm, *Bs = gsm + GC * GLD;
+    const SolveDesc d = sd[first + blockIdx.z / batch];
+    const int b = blockIdx.z % batch;
+    const int r = d.r, w = d.w, nb = r - w;
+    const int i0 = blockIdx.x * GC;
+    if (i0 >= w) return;
+    const int n0 = blockIdx.y * GC, nlive = min(GC, nrhs - n0);
+    const double *pool = pool_all + (long long) b * pool_stride;
+    const double *X = X_all + (long long) b * x_stride;
+    double *V = gv_all + (long long) b * gv_stride + d.gv * (long long) nrhs;
+    const int *st = st_idx + d.st;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, mi = lane & 15, mq = lane >> 4;
+    double4_t acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = i0 + 16 * wv + mq + 4 * v, n = 16 * nt + mi;
+            acc[nt][v] = load_if(X, (long long) (d.c0 + i) * nrhs + n0 + n, i < w && n < nlive);
+        }
+    for (int jb = 0; jb < nb; jb += GC) {
+        __syncthreads();
+        for (int e = tid; e < GC * GC; e += 256) {
+            {   // As[k][i] = U(i0 + i, w + jb + k)
+                const int k = (KIND == CS3_LU) ? e >> 6 : e & 63, i = (KIND == CS3_LU) ? e & 63 : e >> 6;
+                const bool in = i0 + i < w && jb + k < nb;
+                const long long off = (KIND == CS3_LU) ? d.upan + (long long) (i0 + i) * d.u_sk + (long long) (jb + k) * d.u_sj
+                                                       : d.lpan + (long long) (w + jb + k) + (long long) (i0 + i) * r;
+                As[k * GLD + i] = load_if(pool, off, in);
+            }
+            {   // Bs[k][n] = X(row of ancestor w + jb + k, n0 + n)
+                const int k = e >> 6, n = e & 63;
+                const bool in = jb + k < nb && n < nlive;
+                const int row = st[in ? w + jb + k : 0];
+                Bs[k * GLD + n] = load_if(X, (long long) row * nrhs + n0 + n, in);
+            }
+        }
+        __syncthreads();
+        gemm64<true>(As, Bs, acc, wv, mi, mq);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = i0 + 16 * wv + mq + 4 * v, n = 16 * nt + mi;
+            if (i < w && n < nlive) V[(long long) i * nrhs + n0 + n] = acc[nt][v];
+        }
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256)
+k_gemm_bwd(const SolveDesc *__restrict__ sd, int first, int chunk_from_right,
+           const double *__restrict__ pool_all, const double *__restrict__ dinv_all, double *__restrict__ X_all,
+           double *__restrict__ gv_all, int nrhs, long long pool_stride, long long dinv_stride, long long x_stride,
+           long long gv_stride, int batch, XMap xm)
+{
+    extern __shared__ __attribute__((aligned(16))) double gsm[];
+    double *As = gsm, *Bs = gsm + GC * GLD;
+    const SolveDesc d = sd[first + blockIdx.z / batch];
+    const int b = blockIdx.z % batch;
+    const int r = d.r, w = d.w;
+    const int nchunk = (w + GC - 1) / GC;
+    const int c = nchunk - 1 - chunk_from_right;
+    if (c < 0) return;
+    const int kb = c * GC, bw = min(GC, w - kb);
+    const int nsl = kb / GC;                                    // 64-row blocks of pivot rows above the chunk
+    if ((int) blockIdx.x > 0 && (int) blockIdx.x >= nsl) return;
+    const int n0 = blockIdx.y * GC, nlive = min(GC, nrhs - n0);
+    const double *L = pool_all + (long long) b * pool_stride + d.lpan;
+    const double *Uinv = dinv_all + (long long) b * dinv_stride + d.dinv + (long long) c * 2 * GC * GC + GC * GC;
+    double *V = gv_all + (long long) b * gv_stride + d.gv * (long long) nrhs;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, mi = lane & 15, mq = lane >> 4;
+    const bool has_rows = nsl > 0;
+    const int row0 = blockIdx.x * GC;
+    double ra[16], rb[16], rl[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = tid + 256 * q;
+        {
+            const int k = e >> 6, i = e & 63;
+            ra[q] = Uinv[e];
+            rb[q] = load_if(V, (long long) (kb + k) * nrhs + n0 + i, k < bw && i < nlive);
+        }
+        {   // U(row0 + i, kb + k); Cholesky: L(kb + k, row0 + i), k contiguous in memory
+            const int k = (KIND == CS3_LU) ? e >> 6 : e & 63, i = (KIND == CS3_LU) ? e & 63 : e >> 6;
+            const long long off = (KIND == CS3_LU) ? (long long) (row0 + i) + (long long) (kb + k) * r
+                                                   : (long long) (kb + k) + (long long) (row0 + i) * r;
+            rl[q] = load_if(L, off, has_rows && row0 + i < kb && k < bw);
+        }
+    }
+    double4_t acc2[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int row = row0 + 16 * wv + mq + 4 * v, n = 16 * nt + mi;
+            acc2[nt][v] = load_if(V, (long long) row * nrhs + n0 + n, has_rows && row < kb && n < nlive);
+        }
+    // ---- Y = Uinv_cc V_c
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = tid + 256 * q, k = e >> 6, i = e & 63;
+        As[k * GLD + i] = ra[q];
+        Bs[k * GLD + i] = rb[q];
+    }
+    __syncthreads();
+    double4_t acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = double4_t{0.0, 0.0, 0.0, 0.0};
+    gemm64<false>(As, Bs, acc, wv, mi, mq);
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Bs[(16 * wv + mq + 4 * v) * GLD + 16 * nt + mi] = acc[nt][v];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = tid + 256 * q;
+        const int k = (KIND == CS3_LU) ? e >> 6 : e & 63, i = (KIND == CS3_LU) ? e & 63 : e >> 6;
+        As[k * GLD + i] = rl[q];
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        double *X = X_all + (long long) b * x_stride;
+        double *Xo = xm.dst ? xm.dst + (long long) b * x_stride : nullptr;     // fused permutation: row q[k] of the caller's array
+        for (int e = tid; e < GC * GC; e += 256) {
+            const int k = e >> 6, n = e & 63;
+            if (k < bw && n < nlive) {
+                X[(long long) (d.c0 + kb + k) * nrhs + n0 + n] = Bs[k * GLD + n];
+                if (Xo) Xo[(long long) xm.q[d.c0 + kb + k] * nrhs + n0 + n] = Bs[k * GLD + n];
+            }
+        }
+    }
+    if (!has_rows) return;
+    // ---- my 64 pivot rows above the chunk:  V_rows -= U(rows, chunk) Y
+    gemm64<true>(As, Bs, acc2, wv, mi, mq);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int row = row0 + 16 * wv + mq + 4 * v, n = 16 * nt + mi;
+            if (row < kb && n < nlive) V[(long long) row * nrhs + n0 + n] = acc2[nt][v];
+        }
+}
+
 // ----------------------------------------------------------- permutations --
 // dst[k, :] = src[q[k], :]  (gather) or dst[q[k], :] = src[k, :] (scatter)
 __global__ void __launch_bounds__(256)
@@ -2494,6 +2837,8 @@ hipError_t launch_stack_4_by_4(int an, int bn, int am, int bm, const int *Ap, co
 }
 
 // ================================================================ launchers ==
+constexpr int RHS_LANES_MIN = 16;          // from this many right-hand sides on, SK_SMALL fronts run lane = right-hand side
+                                           //   and the fronts of order > 64 sweep as GEMMs
 #define CS3_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
 static int grid_for(long long work, int block, int cap = 4096)
@@ -2603,6 +2948,13 @@ hipError_t prepare_kernels()
                                (const void *) k_front_block<CS3_LU, 8>, (const void *) k_front_block<CS3_CHOLESKY, 8>,
                                (const void *) k_front_wg<CS3_LU>, (const void *) k_front_wg<CS3_CHOLESKY>};
     for (const void *f : block_fns) {
+        e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        if (e != hipSuccess) return e;
+    }
+    const void *gemm_fns[] = {(const void *) k_gemm_fwd<CS3_LU>, (const void *) k_gemm_fwd<CS3_CHOLESKY>,
+                              (const void *) k_gemm_bwd<CS3_LU>, (const void *) k_gemm_bwd<CS3_CHOLESKY>,
+                              (const void *) k_gemm_bwd_init<CS3_LU>, (const void *) k_gemm_bwd_init<CS3_CHOLESKY>};
+    for (const void *f : gemm_fns) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, big);
         if (e != hipSuccess) return e;
     }
@@ -2776,19 +3128,94 @@ static hipError_t launch_bwd_big_chunk(const DeviceFactor &D, const LaunchGroup 
     return hipSuccess;
 }
 
-constexpr int RHS_LANES_MIN = 16;          // from this many right-hand sides on, SK_SMALL fronts run lane = right-hand side
+
+// GEMM sweeps of a group of fronts of order > 64 (SK_WAVE, SK_BLOCK, SK_BIG) for many right-hand sides.
+// Inverted 64 x 64 diagonal blocks of the fronts of order > 64: tasks [t0, t1) of the list (solve-schedule order).
+template <int KIND>
+static hipError_t launch_inv_tasks(const DeviceFactor &D, int t0, int t1, hipStream_t st)
+{
+    if (t1 <= t0) return hipSuccess;
+    hipLaunchKernelGGL((k_inv_diag<KIND>), dim3((unsigned) (t1 - t0), (unsigned) D.batch), dim3(256), 0, st, D.sdesc, D.inv_tasks, t0,
+                       D.pool_pm, D.pm_stride, D.dinv, D.dinv_size);
+    CS3_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+// The permutations can ride on the sweeps when every pivot row of X is read (forward) and written (backward) by a kernel
+// that knows the row map: the lane = right-hand-side kernels and the GEMM sweeps, i.e. 16 or more right-hand sides, no
+// interleaved batch, GEMM sweeps on.
+bool permutation_can_fuse(const DeviceFactor &D, int nrhs)
+{
+    static const bool on = !(getenv("CS3_NO_FUSED_PERMUTE") && getenv("CS3_NO_FUSED_PERMUTE")[0] == '1') &&
+                           !(getenv("CS3_NO_GEMM_SWEEPS") && getenv("CS3_NO_GEMM_SWEEPS")[0] == '1');
+    // (measured on config 4: the extra row-map round trip per front costs more than the two permutation kernels below a
+    // few hundred right-hand sides; at 1024 the fused form saves 0.14 ms of 2.3)
+    static const int min_rhs = getenv("CS3_FUSED_PERMUTE_MIN_RHS") ? atoi(getenv("CS3_FUSED_PERMUTE_MIN_RHS")) : 256;
+    return on && nrhs >= std::max(min_rhs, RHS_LANES_MIN) && D.il_len == 0;
+}
+
+hipError_t launch_diag_inverses(const DeviceFactor &D, hipStream_t st)
+{
+    return (D.kind == CS3_LU) ? launch_inv_tasks<CS3_LU>(D, 0, D.n_inv_tasks, st) : launch_inv_tasks<CS3_CHOLESKY>(D, 0, D.n_inv_tasks, st);
+}
+
+// with_inverse: compute this group's inverted diagonal blocks first (the fused factor + solve graph, where they cannot
+// be prepared ahead of the factorisation); otherwise the caller has run launch_diag_inverses since the last factorisation.
+template <int KIND>
+static hipError_t launch_gemm_group(const DeviceFactor &D, const LaunchGroup &g, double *X, int nrhs, bool forward, bool with_inverse,
+                                    hipStream_t st)
+{
+    const long long xs = D.n * (long long) nrhs, cvs = D.cv_size * (long long) nrhs, gvs = D.gv_size * (long long) nrhs;
+    const unsigned batch = (unsigned) D.batch, tiles = (unsigned) ((nrhs + GC - 1) / GC);
+    // the inverted diagonal blocks of this group's fronts: tasks are in solve-schedule order
+    int t0 = 0, t1 = 0;
+    {
+        const std::vector<int> &T = D.inv_tasks_host;
+        const int nt = (int) (T.size() / 2);
+        while (t0 < nt && T[2 * t0] < g.first) ++t0;
+        t1 = t0;
+        while (t1 < nt && T[2 * t1] < g.first + g.count) ++t1;
+    }
+    if (with_inverse) {
+        hipError_t ie = launch_inv_tasks<KIND>(D, t0, t1, st);
+        if (ie != hipSuccess) return ie;
+    }
+    const int nchunk = (g.max_w + GC - 1) / GC;
+    const unsigned slices = (unsigned) std::max(1, (g.max_r + GC - 1) / GC);
+    if (forward) {
+        hipLaunchKernelGGL(k_gemm_gather, dim3(4, batch * (unsigned) nrhs, g.count), dim3(256), 0, st, D.sdesc, g.first, D.fasm_src,
+                           D.fasm_tgt, D.flong_src, D.cv, X, D.gv, nrhs, cvs, xs, gvs, D.xm);
+        CS3_LAUNCH_CHECK();
+        for (int c = 0; c < nchunk; ++c) {
+            hipLaunchKernelGGL((k_gemm_fwd<KIND>), dim3(slices, tiles, g.count * batch), dim3(256), GEMM_LDS, st, D.sdesc, g.first, c,
+                               D.pool_pm, D.dinv, D.cv, X, D.gv, nrhs, D.pm_stride, D.dinv_size, cvs, xs, gvs, (int) batch);
+            CS3_LAUNCH_CHECK();
+        }
+    } else {
+        hipLaunchKernelGGL((k_gemm_bwd_init<KIND>), dim3((unsigned) nchunk, tiles, g.count * batch), dim3(256), GEMM_LDS, st, D.sdesc,
+                           g.first, D.st_idx, D.pool_pm, X, D.gv, nrhs, D.pm_stride, xs, gvs, (int) batch);
+        CS3_LAUNCH_CHECK();
+        for (int c = 0; c < nchunk; ++c) {
+            hipLaunchKernelGGL((k_gemm_bwd<KIND>), dim3((unsigned) std::max(1, nchunk), tiles, g.count * batch), dim3(256), GEMM_LDS, st,
+                               D.sdesc, g.first, c, D.pool_pm, D.dinv, X, D.gv, nrhs, D.pm_stride, D.dinv_size, xs, gvs, (int) batch, D.xm);
+            CS3_LAUNCH_CHECK();
+        }
+    }
+    return hipSuccess;
+}
 
 template <int KIND, int RMAX>
-static void launch_rhs_sweep(const DeviceFactor &D, const LaunchGroup &g, double *X, int nrhs, bool forward, hipStream_t st)
+static void launch_rhs_sweep(const DeviceFactor &D, int first, int count, double *X, int nrhs, bool forward, hipStream_t st)
 {
+    if (count <= 0) return;
     const long long xs = D.n * (long long) nrhs, cvs = D.cv_size * (long long) nrhs;
-    dim3 grid((unsigned) g.count, (unsigned) D.batch, (unsigned) ((nrhs + 63) / 64));
+    dim3 grid((unsigned) count, (unsigned) D.batch, (unsigned) ((nrhs + 63) / 64));
     if (forward)
-        hipLaunchKernelGGL((k_fwd_rhs<KIND, RMAX>), grid, dim3(64), 0, st, D.sdesc, g.first, D.rl_pairs, D.pool_pm, D.cv, X,
-                           nrhs, D.pm_stride, cvs, xs);
+        hipLaunchKernelGGL((k_fwd_rhs<KIND, RMAX>), grid, dim3(64), 0, st, D.sdesc, first, D.rl_pairs, D.pool_pm, D.cv, X,
+                           nrhs, D.pm_stride, cvs, xs, D.xm);
     else
-        hipLaunchKernelGGL((k_bwd_rhs<KIND, RMAX>), grid, dim3(64), 0, st, D.sdesc, g.first, D.st_idx, D.pool_pm, X,
-                           nrhs, D.pm_stride, xs);
+        hipLaunchKernelGGL((k_bwd_rhs<KIND, RMAX>), grid, dim3(64), 0, st, D.sdesc, first, D.st_idx, D.pool_pm, X,
+                           nrhs, D.pm_stride, xs, D.xm);
 }
 
 template <int KIND>
@@ -2797,6 +3224,9 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
 {
     const long long xs = D.n * (long long) nrhs;
     const long long cvs = D.cv_size * (long long) nrhs;
+    static const bool use_gemm = !(getenv("CS3_NO_GEMM_SWEEPS") && getenv("CS3_NO_GEMM_SWEEPS")[0] == '1');
+    if (use_gemm && nrhs >= RHS_LANES_MIN && (g.cls == SK_WAVE || g.cls == SK_BLOCK || g.cls == SK_BIG))
+        return launch_gemm_group<KIND>(D, g, X, nrhs, forward, forward && D.inverses_in_sweep, st);
     if (g.cls == SK_IL) {
         dim3 grid((unsigned) g.count, (unsigned) D.ngroups);
         if (forward)
@@ -2806,9 +3236,17 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
             hipLaunchKernelGGL((k_bwd_il<KIND, IL_RMAX>), grid, dim3(64), 0, st, D.sdesc, g.first, D.st_idx,
                                IlView{D.pool_il, D.il_len}, X, nrhs, xs, (int) D.batch);
     } else if (g.cls == SK_SMALL && nrhs >= RHS_LANES_MIN) {
-        if (g.max_r <= 24) launch_rhs_sweep<KIND, 24>(D, g, X, nrhs, forward, st);
-        else if (g.max_r <= 32) launch_rhs_sweep<KIND, 32>(D, g, X, nrhs, forward, st);
-        else launch_rhs_sweep<KIND, 64>(D, g, X, nrhs, forward, st);
+        // the fronts of order <= 16 come first in the group: half the registers and LDS per wave, twice the waves per CU
+        // (these sweeps are bound by memory latency times occupancy); the two launches are independent
+        static const bool split16 = !(getenv("CS3_NO_SPLIT16") && getenv("CS3_NO_SPLIT16")[0] == '1');
+        // (forward only: the backward kernel keeps no vector in LDS and its 24-row instance already runs 5 waves per SIMD)
+        const int n16 = (split16 && forward && nrhs >= 256 && g.max_r > 16) ? g.n16 : 0;     // (an extra launch per level: pays with many tiles)
+        if (n16 > 0) launch_rhs_sweep<KIND, 16>(D, g.first, n16, X, nrhs, forward, st);
+        const int f2 = g.first + n16, c2 = g.count - n16;
+        if (g.max_r <= 16 && forward) launch_rhs_sweep<KIND, 16>(D, f2, c2, X, nrhs, forward, st);
+        else if (g.max_r <= 24) launch_rhs_sweep<KIND, 24>(D, f2, c2, X, nrhs, forward, st);
+        else if (g.max_r <= 32) launch_rhs_sweep<KIND, 32>(D, f2, c2, X, nrhs, forward, st);
+        else launch_rhs_sweep<KIND, 64>(D, f2, c2, X, nrhs, forward, st);
     } else if (g.cls == SK_SMALL || g.cls == SK_WAVE) {
         if (nrhs == 1) {
             dim3 grid((unsigned) ((g.count + 3) / 4), (unsigned) D.batch, 1);
@@ -2879,6 +3317,10 @@ hipError_t launch_solve_levels(const DeviceFactor &D, const std::vector<LaunchGr
                                   : launch_solve_group<CS3_CHOLESKY>(D, g, X, nrhs, forward, s);
     };
     if (forward) {
+        if (nrhs >= RHS_LANES_MIN && D.gv_size > 0) {         // rows of a front vector that no source touches start at zero
+            hipError_t me = hipMemsetAsync(D.gv, 0, (size_t) (D.batch * D.gv_size * nrhs) * sizeof(double), st);
+            if (me != hipSuccess) return me;
+        }
         for (size_t g0 = 0; g0 < groups.size(); ) {
             size_t g1 = g0;
             while (g1 < groups.size() && groups[g1].level == groups[g0].level) ++g1;
@@ -2920,6 +3362,9 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
     const std::vector<LaunchGroup> sgroups = sweep_groups(all_sgroups, nrhs);
     fj.rewind();
     hipError_t e;
+    if (nrhs >= RHS_LANES_MIN && D.gv_size > 0) {             // front vectors of the GEMM sweeps start at zero
+        if ((e = hipMemsetAsync(D.gv, 0, (size_t) (D.batch * D.gv_size * nrhs) * sizeof(double), st)) != hipSuccess) return e;
+    }
     const int nlevels = fgroups.empty() ? 0 : fgroups.back().level + 1;
     std::vector<long long> tail(nlevels + 1, 0), head(nlevels + 1, 0);   // factor cost of levels >= l; sweep cost of levels < l
     for (const LaunchGroup &g : fgroups) tail[g.level] += factor_group_cost(g);
@@ -2946,7 +3391,8 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
     // later blocks are still being factorised.
     const LaunchGroup *rootf = nullptr, *roots = nullptr;
     static const bool pipe_root = !(getenv("CS3_NO_ROOT_PIPE") && getenv("CS3_NO_ROOT_PIPE")[0] == '1');
-    if (pipe_root && nlevels >= 2 && fork_level == nlevels - 2) {
+    // (with many right-hand sides the root sweeps as GEMMs through launch_solve_group like every other group)
+    if (pipe_root && nrhs < RHS_LANES_MIN && nlevels >= 2 && fork_level == nlevels - 2) {
         int nf = 0, ns = 0;
         for (const LaunchGroup &g : fgroups) if (g.level == nlevels - 1) { ++nf; rootf = &g; }
         for (const LaunchGroup &g : sgroups) if (g.level == nlevels - 1) { ++ns; roots = &g; }

@@ -662,8 +662,21 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     std::iota(S.ssched.begin(), S.ssched.end(), 0);
     std::stable_sort(S.ssched.begin(), S.ssched.end(), [&](i32 a, i32 b) {
         if (S.sn_level[a] != S.sn_level[b]) return S.sn_level[a] < S.sn_level[b];
-        return solve_kind(a) < solve_kind(b);
+        if (solve_kind(a) != solve_kind(b)) return solve_kind(a) < solve_kind(b);
+        return (order_r(a) <= 16) > (order_r(b) <= 16);          // fronts of order <= 16 first inside a group
     });
+    // GEMM sweeps (many right-hand sides) of the fronts beyond the lane = right-hand-side kernels
+    S.gv_off.assign(ns, 0); S.dinv_off.assign(ns, 0); S.gv_size = 0; S.dinv_size = 0; S.inv_tasks.clear();
+    for (i32 t = 0; t < ns; ++t) {
+        const i32 s = S.ssched[t];
+        const int sk = solve_kind(s);
+        if (sk != SK_WAVE && sk != SK_BLOCK && sk != SK_BIG) continue;
+        S.gv_off[s] = S.gv_size; S.gv_size += order_r(s);
+        S.dinv_off[s] = S.dinv_size;
+        const i64 nchunk = (width(s) + 63) / 64;
+        S.dinv_size += nchunk * 2 * 4096;
+        for (i64 c = 0; c < nchunk; ++c) { S.inv_tasks.push_back(t); S.inv_tasks.push_back((i32) c); }
+    }
     S.sgroups.clear();
     for (i32 t = 0; t < ns; ) {
         i32 s = S.ssched[t];
@@ -672,6 +685,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
             const i32 f = S.ssched[t];
             g.max_r = std::max<i32>(g.max_r, (i32) order_r(f));
             g.max_w = std::max<i32>(g.max_w, (i32) width(f));
+            if (order_r(f) <= 16) ++g.n16;
             ++t;
         }
         g.count = t - g.first;

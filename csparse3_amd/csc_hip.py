@@ -118,6 +118,8 @@ def lib():
         L.cs3_csc_usolve.argtypes = [I64, _i32p, _i32p, _f64p, _f64p, I64]
         L.cs3_csc_matvec.argtypes = [I64, I64, _i32p, _i32p, _f64p, _f64p, _f64p, I64]
         L.cs3_csc_stack_4_by_4.argtypes = [I64, I64, _i32p, _i32p, _f64p] * 4 + [_i32p, _i32p, _f64p]
+        L.cs3_csc_stack_4_by_4_dev.argtypes = [I64, I64, I64, vp, vp, vp] * 4 + [vp, vp, vp, vp, vp]
+        L.cs3_restack_values_dev.argtypes = [I64, vp, I64, I64, I64, vp, vp, vp, vp, vp, vp]
         L.cs3_csc_transpose.argtypes = [I64, I64, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p]
         L.cs3_coo_to_csc.argtypes = [I64, I64, I64, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p]
         L.cs3_csc_norm.argtypes = [I64, _i32p, _f64p, C.POINTER(C.c_double)]
@@ -406,6 +408,23 @@ def csc_stack_4_by_4_ff(am, an, Ai, Ap, Ax, bm, bn, Bi, Bp, Bx, cm, cn, Ci, Cp, 
                                       cm, cn, _pi(a[6]), _pi(a[7]), _pf(a[8]), dm, dn, _pi(a[9]), _pi(a[10]), _pf(a[11]),
                                       _pi(Pi), _pi(Pp), _pf(Px)))
     return am + cm, an + bn, Pi, Pp, Px
+
+
+def csc_stack_4_by_4_dev(blocks, Pi_ptr, Pp_ptr, Px_ptr, map_ptr=0, stream=0):
+    """csc_stack_4_by_4_ff on arrays that already live in HBM.  blocks = [(m, n, nnz, indices_ptr, indptr_ptr, data_ptr)] * 4
+    for A, B, C, D (device addresses, e.g. torch.Tensor.data_ptr()); outputs are device addresses too.  Asynchronous on
+    `stream`; nothing crosses PCIe.  map_ptr (optional, int32[nnz]) receives the restack map for restack_values_dev."""
+    args = []
+    for (m, n, nnz, pi, pp, px) in blocks:
+        args += [m, n, nnz, C.c_void_p(pi), C.c_void_p(pp), C.c_void_p(px)]
+    _check(lib().cs3_csc_stack_4_by_4_dev(*args, C.c_void_p(Pi_ptr), C.c_void_p(Pp_ptr), C.c_void_p(Px_ptr),
+                                          C.c_void_p(map_ptr), C.c_void_p(stream)))
+
+
+def restack_values_dev(nnz, map_ptr, nnz_a, nnz_b, nnz_c, ax_ptr, bx_ptr, cx_ptr, dx_ptr, px_ptr, stream=0):
+    """Px[p] = (A | B | C | D)[map[p]]: the values-only restack of a Newton iteration (patterns unchanged)."""
+    _check(lib().cs3_restack_values_dev(nnz, C.c_void_p(map_ptr), nnz_a, nnz_b, nnz_c, C.c_void_p(ax_ptr), C.c_void_p(bx_ptr),
+                                        C.c_void_p(cx_ptr), C.c_void_p(dx_ptr), C.c_void_p(px_ptr), C.c_void_p(stream)))
 
 
 # ---- format conversions and utilities on the device (SURVEY.md section 8f) ------------------------

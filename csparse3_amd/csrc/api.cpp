@@ -845,12 +845,46 @@ int cs3_csc_stack_4_by_4(int64_t am, int64_t an, const int32_t *Ai, const int32_
     if (e == hipSuccess)
         e = launch_stack_4_by_4((int) an, (int) bn, (int) am, (int) bm, blk[0].dp, blk[0].di, blk[0].dx, blk[1].dp, blk[1].di,
                                 blk[1].dx, blk[2].dp, blk[2].di, blk[2].dx, blk[3].dp, blk[3].di, blk[3].dx, d_pp, d_pi, d_px,
-                                nullptr);
+                                nullptr, nullptr);
     if (e == hipSuccess) e = hipMemcpy(Pp, d_pp, (size_t) (ncol + 1) * sizeof(int), hipMemcpyDeviceToHost);
     if (e == hipSuccess && nnz) e = hipMemcpy(Pi, d_pi, (size_t) nnz * sizeof(int), hipMemcpyDeviceToHost);
     if (e == hipSuccess && nnz) e = hipMemcpy(Px, d_px, (size_t) nnz * sizeof(double), hipMemcpyDeviceToHost);
     cleanup();
     CS3_HIP(e);
+    return CS3_OK;
+}
+
+// The same on data that already lives in HBM: nothing crosses PCIe and nothing synchronises.  The caller knows the
+// blocks' entry counts (it allocated them) and passes them, so no column pointer has to come back to the host.
+int cs3_csc_stack_4_by_4_dev(int64_t am, int64_t an, int64_t nnz_a, const int32_t *Ai, const int32_t *Ap, const double *Ax,
+                             int64_t bm, int64_t bn, int64_t nnz_b, const int32_t *Bi, const int32_t *Bp, const double *Bx,
+                             int64_t cm, int64_t cn, int64_t nnz_c, const int32_t *Ci, const int32_t *Cp, const double *Cx,
+                             int64_t dm, int64_t dn, int64_t nnz_d, const int32_t *Di, const int32_t *Dp, const double *Dx,
+                             int32_t *Pi, int32_t *Pp, double *Px, int32_t *map, void *stream)
+{
+    if (am != bm || cm != dm || an != cn || bn != dn) { set_error("cs3_csc_stack_4_by_4_dev: incompatible block shapes"); return CS3_ERR_ARG; }
+    if (!Ap || !Bp || !Cp || !Dp || !Pp) { set_error("cs3_csc_stack_4_by_4_dev: null argument"); return CS3_ERR_ARG; }
+    const int64_t nnz = nnz_a + nnz_b + nnz_c + nnz_d;
+    if (nnz_a < 0 || nnz_b < 0 || nnz_c < 0 || nnz_d < 0 || nnz > INT_MAX || an + bn > INT_MAX) { set_error("cs3_csc_stack_4_by_4_dev: bad sizes"); return CS3_ERR_ARG; }
+    if (nnz > 0 && (!Pi || !Px)) { set_error("cs3_csc_stack_4_by_4_dev: null output"); return CS3_ERR_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device visible: cs3_csc_stack_4_by_4_dev runs on the GPU only"); return CS3_ERR_HIP;
+    }
+    CS3_HIP(launch_stack_4_by_4((int) an, (int) bn, (int) am, (int) bm, Ap, Ai, Ax, Bp, Bi, Bx, Cp, Ci, Cx, Dp, Di, Dx, Pp, Pi, Px,
+                                map, (hipStream_t) stream));
+    return CS3_OK;
+}
+
+int cs3_restack_values_dev(int64_t nnz, const int32_t *map, int64_t nnz_a, int64_t nnz_b, int64_t nnz_c,
+                           const double *Ax, const double *Bx, const double *Cx, const double *Dx, double *Px, void *stream)
+{
+    if (nnz < 0 || nnz_a < 0 || nnz_b < 0 || nnz_c < 0 || (nnz > 0 && (!map || !Px))) { set_error("cs3_restack_values_dev: bad argument"); return CS3_ERR_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device visible: cs3_restack_values_dev runs on the GPU only"); return CS3_ERR_HIP;
+    }
+    CS3_HIP(launch_restack_values(nnz, map, nnz_a, nnz_b, nnz_c, Ax, Bx, Cx, Dx, Px, (hipStream_t) stream));
     return CS3_OK;
 }
 

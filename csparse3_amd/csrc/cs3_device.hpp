@@ -130,7 +130,9 @@ hipError_t launch_tri_level(const int *rows, int nrows, const int *Rp, const int
 hipError_t launch_stack_4_by_4(int an, int bn, int am, int bm, const int *Ap, const int *Ai, const double *Ax,
                                const int *Bp, const int *Bi, const double *Bx, const int *Cp, const int *Ci,
                                const double *Cx, const int *Dp, const int *Di, const double *Dx,
-                               int *Pp, int *Pi, double *Px, hipStream_t st);
+                               int *Pp, int *Pi, double *Px, int *map, hipStream_t st);
+hipError_t launch_restack_values(long long nnz, const int *map, long long na, long long nb, long long nc, const double *Ax,
+                                 const double *Bx, const double *Cx, const double *Dx, double *Px, hipStream_t st);
 hipError_t launch_matvec_rows(const int *Rp, const int *Rj, const double *Rx, const double *X, double *Y,
                               long long m, int nrhs, hipStream_t st);
 

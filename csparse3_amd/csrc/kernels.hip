@@ -2801,7 +2801,7 @@ k_stack_4_by_4(int an, int bn, int am, int bm,
                const int *__restrict__ Bp, const int *__restrict__ Bi, const double *__restrict__ Bx,
                const int *__restrict__ Cp, const int *__restrict__ Ci, const double *__restrict__ Cx,
                const int *__restrict__ Dp, const int *__restrict__ Di, const double *__restrict__ Dx,
-               int *__restrict__ Pp, int *__restrict__ Pi, double *__restrict__ Px)
+               int *__restrict__ Pp, int *__restrict__ Pi, double *__restrict__ Px, int *__restrict__ map)
 {
     const int col = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
@@ -2815,8 +2815,16 @@ k_stack_4_by_4(int an, int bn, int am, int bm,
     const int base = left ? 0 : Ap[an] + Cp[an];
     const int out0 = base + Tp[j] + Bp2[j];
     const int n1 = Tp[j + 1] - Tp[j], n2 = Bp2[j + 1] - Bp2[j];
-    for (int k = lane; k < n1; k += 64) { Pi[out0 + k] = Ti[Tp[j] + k]; Px[out0 + k] = Tx[Tp[j] + k]; }
-    for (int k = lane; k < n2; k += 64) { Pi[out0 + n1 + k] = Bi2[Bp2[j] + k] + shift; Px[out0 + n1 + k] = Bx2[Bp2[j] + k]; }
+    // position of the source entry in the concatenation A | B | C | D of the value arrays (the restack map)
+    const int cat1 = left ? 0 : Ap[an], cat2 = left ? Ap[an] + Bp[bn] : Ap[an] + Bp[bn] + Cp[an];
+    for (int k = lane; k < n1; k += 64) {
+        Pi[out0 + k] = Ti[Tp[j] + k]; Px[out0 + k] = Tx[Tp[j] + k];
+        if (map) map[out0 + k] = cat1 + Tp[j] + k;
+    }
+    for (int k = lane; k < n2; k += 64) {
+        Pi[out0 + n1 + k] = Bi2[Bp2[j] + k] + shift; Px[out0 + n1 + k] = Bx2[Bp2[j] + k];
+        if (map) map[out0 + n1 + k] = cat2 + Bp2[j] + k;
+    }
     if (lane == 0) {
         Pp[col + 1] = out0 + n1 + n2;
         if (col == 0) Pp[0] = 0;
@@ -2826,14 +2834,35 @@ k_stack_4_by_4(int an, int bn, int am, int bm,
 hipError_t launch_stack_4_by_4(int an, int bn, int am, int bm, const int *Ap, const int *Ai, const double *Ax,
                                const int *Bp, const int *Bi, const double *Bx, const int *Cp, const int *Ci,
                                const double *Cx, const int *Dp, const int *Di, const double *Dx,
-                               int *Pp, int *Pi, double *Px, hipStream_t st)
+                               int *Pp, int *Pi, double *Px, int *map, hipStream_t st)
 {
     const int ncol = an + bn;
     if (ncol == 0) return hipSuccess;
     hipLaunchKernelGGL(k_stack_4_by_4, dim3((ncol + 3) / 4), dim3(256), 0, st, an, bn, am, bm, Ap, Ai, Ax, Bp, Bi, Bx,
-                       Cp, Ci, Cx, Dp, Di, Dx, Pp, Pi, Px);
+                       Cp, Ci, Cx, Dp, Di, Dx, Pp, Pi, Px, map);
     hipError_t e = hipGetLastError();
     return e;
+}
+
+// Px[p] = value at position map[p] of the concatenation A | B | C | D: the Newton-loop restack (pattern unchanged)
+__global__ void __launch_bounds__(256)
+k_restack_values(long long nnz, const int *__restrict__ map, long long na, long long nb, long long nc,
+                 const double *__restrict__ Ax, const double *__restrict__ Bx, const double *__restrict__ Cx,
+                 const double *__restrict__ Dx, double *__restrict__ Px)
+{
+    for (long long p = (long long) blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += (long long) gridDim.x * blockDim.x) {
+        const long long s = map[p];
+        Px[p] = (s < na) ? Ax[s] : (s < na + nb) ? Bx[s - na] : (s < na + nb + nc) ? Cx[s - na - nb] : Dx[s - na - nb - nc];
+    }
+}
+
+hipError_t launch_restack_values(long long nnz, const int *map, long long na, long long nb, long long nc, const double *Ax,
+                                 const double *Bx, const double *Cx, const double *Dx, double *Px, hipStream_t st)
+{
+    if (nnz == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_restack_values, dim3((unsigned) std::min<long long>((nnz + 255) / 256, 4096)), dim3(256), 0, st, nnz, map,
+                       na, nb, nc, Ax, Bx, Cx, Dx, Px);
+    return hipGetLastError();
 }
 
 // ================================================================ launchers ==

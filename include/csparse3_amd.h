@@ -181,6 +181,21 @@ int cs3_csc_stack_4_by_4(int64_t am, int64_t an, const int32_t *Ai, const int32_
                          int64_t dm, int64_t dn, const int32_t *Di, const int32_t *Dp, const double *Dx,
                          int32_t *Pi, int32_t *Pp, double *Px);
 
+/* The same with every array already in HBM (device pointers in and out, asynchronous on `stream`): the Jacobian is
+ * assembled where the factorisation reads it, so  stack -> cs3_factor_solve_dev  runs without a host copy.  nnz_* are
+ * the blocks' entry counts (Ap[an] ...), passed by the caller so that nothing has to come back to the host.
+ * map (optional, [nnz]): position of every output entry in the concatenation A | B | C | D of the value arrays. */
+int cs3_csc_stack_4_by_4_dev(int64_t am, int64_t an, int64_t nnz_a, const int32_t *Ai_dev, const int32_t *Ap_dev, const double *Ax_dev,
+                             int64_t bm, int64_t bn, int64_t nnz_b, const int32_t *Bi_dev, const int32_t *Bp_dev, const double *Bx_dev,
+                             int64_t cm, int64_t cn, int64_t nnz_c, const int32_t *Ci_dev, const int32_t *Cp_dev, const double *Cx_dev,
+                             int64_t dm, int64_t dn, int64_t nnz_d, const int32_t *Di_dev, const int32_t *Dp_dev, const double *Dx_dev,
+                             int32_t *Pi_dev, int32_t *Pp_dev, double *Px_dev, int32_t *map_dev, void *stream);
+/* Newton-loop restack: the blocks' patterns have not changed, only their values -- Px[p] = (A | B | C | D)[map[p]] with the
+ * map of the first stacking.  One gather kernel; its output is what cs3_factor_solve_dev takes as Ax_dev. */
+int cs3_restack_values_dev(int64_t nnz, const int32_t *map_dev, int64_t nnz_a, int64_t nnz_b, int64_t nnz_c,
+                           const double *Ax_dev, const double *Bx_dev, const double *Cx_dev, const double *Dx_dev,
+                           double *Px_dev, void *stream);
+
 /* ---- format conversions and utilities on the device ----
  * Same outputs as the reference's Python kernels, bit for bit (tests/golden/): output ORDER included.
  * Host pointers in and out; results are caller-allocated. */

@@ -146,3 +146,68 @@ def test_substrate_rejects_bad_indices(gpu):
     _, _, Tp, Ti, Tx = gpu.csc_transpose(3, 3, z, np.zeros(0, dtype=np.int32), np.zeros(0))
     assert np.array_equal(Tp, z) and len(Ti) == 0 and gpu.csc_norm(3, z, np.zeros(0)) == 0.0
     assert [list(x) for x in gpu.find_islands(3, z, np.zeros(0, dtype=np.int32))] == [[0], [1], [2]]
+
+
+# ----------------------------------------------- device-resident assembly -> refactor -> solve ----
+
+def _jacobian_blocks():
+    """The config-2 Jacobian cut into the four blocks pack_4_by_4 stacks (csc.py:588-606): [[H, N], [M, L]]."""
+    import scipy.sparse as sp
+    from csparse3_amd import synth
+    m, n, Ap, Ai, Ax = synth.jacobian_config2()
+    J = sp.csc_matrix((Ax, Ai, Ap), shape=(n, n))
+    k = 219                                                 # pvpq unknowns of the 220-bus case
+    blocks = []
+    for rs, cs in ((slice(0, k), slice(0, k)), (slice(0, k), slice(k, n)), (slice(k, n), slice(0, k)), (slice(k, n), slice(k, n))):
+        Bk = J[rs, cs].tocsc(); Bk.sort_indices()
+        blocks.append((Bk.shape[0], Bk.shape[1], Bk.indices.astype(np.int32), Bk.indptr.astype(np.int32), Bk.data.copy()))
+    return (m, n, Ap, Ai, Ax), blocks
+
+
+def test_device_resident_stack_refactor_solve_chain(gpu):
+    """Newton-loop shape on resident data: stack the four blocks in HBM (cs3_csc_stack_4_by_4_dev), then per iteration
+    restack the new values through the cached map (cs3_restack_values_dev) and refactor + solve (cs3_factor_solve_bx_dev).
+    Bit-exact with the golden stacking, with the host-pointer stacking, and with the host-pointer factor + solve."""
+    import torch
+    dev = torch.device("cuda", 0)
+    sh = torch.cuda.current_stream().cuda_stream
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    # (i) the reference's own stacking output (tests/golden), on device arrays
+    g = lambda k: GOLD["st_" + k]
+    am, an, bn, cm = int(g("am")), int(g("an")), int(g("bn")), int(g("cm"))
+    blk = [(am, an, g("Ai"), g("Ap"), g("Ax")), (am, bn, g("Bi"), g("Bp"), g("Bx")), (cm, an, g("Ci"), g("Cp"), g("Cx")), (cm, bn, g("Di"), g("Dp"), g("Dx"))]
+    dblk = [(m_, n_, int(p_[n_]), T(i_), T(p_), T(x_)) for (m_, n_, i_, p_, x_) in blk]
+    nnz = sum(b[2] for b in dblk)
+    Pi, Pp, Px = torch.empty(nnz, dtype=torch.int32, device=dev), torch.empty(an + bn + 1, dtype=torch.int32, device=dev), torch.empty(nnz, dtype=torch.float64, device=dev)
+    gpu.csc_stack_4_by_4_dev([(m_, n_, z_, i_.data_ptr(), p_.data_ptr(), x_.data_ptr()) for (m_, n_, z_, i_, p_, x_) in dblk],
+                             Pi.data_ptr(), Pp.data_ptr(), Px.data_ptr(), 0, sh)
+    assert np.array_equal(Pi.cpu().numpy(), g("i")) and np.array_equal(Pp.cpu().numpy(), g("p")) and np.array_equal(Px.cpu().numpy(), g("x"))
+    # (ii) the Jacobian of config 2 from its four blocks, then four Newton-style value updates
+    (m, n, Ap, Ai, Ax), blocks = _jacobian_blocks()
+    dblk = [(m_, n_, int(p_[n_]), T(i_), T(p_), T(x_)) for (m_, n_, i_, p_, x_) in blocks]
+    nz = [b[2] for b in dblk]
+    nnz = sum(nz)
+    Pi, Pp, Px = torch.empty(nnz, dtype=torch.int32, device=dev), torch.empty(n + 1, dtype=torch.int32, device=dev), torch.empty(nnz, dtype=torch.float64, device=dev)
+    mp = torch.empty(nnz, dtype=torch.int32, device=dev)
+    gpu.csc_stack_4_by_4_dev([(m_, n_, z_, i_.data_ptr(), p_.data_ptr(), x_.data_ptr()) for (m_, n_, z_, i_, p_, x_) in dblk],
+                             Pi.data_ptr(), Pp.data_ptr(), Px.data_ptr(), mp.data_ptr(), sh)
+    assert np.array_equal(Pp.cpu().numpy(), Ap) and np.array_equal(Pi.cpu().numpy(), Ai) and np.array_equal(Px.cpu().numpy(), Ax)
+    hm, hn, hPi, hPp, hPx = gpu.csc_stack_4_by_4_ff(*[v for (m_, n_, i_, p_, x_) in blocks for v in (m_, n_, i_, p_, x_)])
+    assert (hm, hn) == (n, n) and np.array_equal(hPi, Ai) and np.array_equal(hPp, Ap) and np.array_equal(hPx, Ax)
+    b = np.random.default_rng(1).standard_normal(n)
+    d_b, d_x = T(b), torch.empty(n, dtype=torch.float64, device=dev)
+    rng = np.random.default_rng(2)
+    with gpu.Factorization(n, n, Ap, Ai) as F, gpu.Factorization(n, n, Ap, Ai) as H:
+        for it in range(4):
+            new = [x_ * (1.0 + 0.02 * rng.uniform(-1.0, 1.0, size=x_.shape)) for (_, _, _, _, x_) in blocks]
+            dnew = [T(v) for v in new]                       # (in a power-flow code these are produced on the device)
+            gpu.restack_values_dev(nnz, mp.data_ptr(), nz[0], nz[1], nz[2], *[v.data_ptr() for v in dnew], Px.data_ptr(), sh)
+            F.factor_solve_bx_dev(Px.data_ptr(), d_b.data_ptr(), d_x.data_ptr(), 1, 1e-3, sh)
+            F.factor_status(sh)
+            # host-pointer path: stack on the host side of the ABI, factor, solve
+            _, _, _, _, hx = gpu.csc_stack_4_by_4_ff(*[v for (blkv, nv) in zip(blocks, new) for v in (blkv[0], blkv[1], blkv[2], blkv[3], nv)])
+            assert np.array_equal(Px.cpu().numpy(), hx)
+            want = H.factor(hx, 1e-3).solve(b)
+            assert np.array_equal(d_x.cpu().numpy(), want)
+            A = csc_to_scipy(n, n, Ap, Ai, hx)
+            assert np.abs(A @ want - b).max() < 1e-10

@@ -243,6 +243,50 @@ k_label_jump(int *label, int n)
     }
 }
 
+// ---- exact find_islands on patterns that are NOT structurally symmetric ------------------------------------------
+// The reference opens an island at the smallest unvisited node s and puts in it every unvisited node reachable from s
+// along column -> row edges (v -> indices[indptr[v] .. indptr[v + 1]), csc_numba.py:768-800).  The visited set is closed
+// under successors, so node i ends up in the island of  m(i) = the smallest node that reaches i  (itself included):
+// nothing smaller reaches m(i), so the loop finds it unvisited and starts there, and no earlier start reaches i.
+// m is the least fixed point of  label[k] <- min(label[k], label[v])  over the edges v -> k; label[i] <- label[label[i]]
+// is valid too (reachability is transitive) and makes chains converge in O(log n) rounds instead of O(n).
+// On a structurally symmetric pattern m(i) is the smallest node of i's connected component: the root-hooking kernels
+// above give the same labels in fewer rounds and are used there.
+__global__ void __launch_bounds__(256)
+k_pattern_symmetric(const int *__restrict__ Ap, const int *__restrict__ Ai, int n, int *unsym)
+{
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+        for (int p = Ap[j]; p < Ap[j + 1]; ++p) {
+            const int i = Ai[p];
+            if (i < 0 || i >= n || i == j) continue;
+            bool found = false;
+            for (int q = Ap[i]; q < Ap[i + 1] && !found; ++q) found = Ai[q] == j;
+            if (!found) { *unsym = 1; return; }
+        }
+}
+
+__global__ void __launch_bounds__(256)
+k_reach_hook(const int *__restrict__ Ap, const int *__restrict__ Ai, int n, int *label, int *changed)
+{
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+        const int lv = label[v];
+        for (int p = Ap[v]; p < Ap[v + 1]; ++p) {
+            const int k = Ai[p];
+            if (k < 0 || k >= n) continue;
+            if (lv < label[k]) { atomicMin(&label[k], lv); *changed = 1; }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_reach_jump(int *label, int n, int *changed)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int l = label[i], ll = label[l];
+        if (ll < l) { atomicMin(&label[i], ll); *changed = 1; }
+    }
+}
+
 static unsigned blocks_for(long long work, int block)
 {
     return (unsigned) std::max<long long>(1, std::min<long long>((work + block - 1) / block, 4096));
@@ -471,7 +515,8 @@ int cs3_csc_sub_matrix(int64_t n, const int32_t *Ap, const int32_t *Ai, const do
     return CS3_OK;
 }
 
-// label[i] = smallest node of the island of node i (find_islands, csc_numba.py:744-808; see above).
+// label[i] = start (= smallest) node of the island that find_islands puts node i in (csc_numba.py:744-808), exact on
+// unsymmetric patterns too (see above).
 int cs3_find_islands(int64_t n, const int32_t *Ap, const int32_t *Ai, int32_t *label)
 {
     if (n < 0 || n > INT_MAX || !Ap || (n > 0 && !label)) { set_error("cs3_find_islands: bad argument"); return CS3_ERR_ARG; }
@@ -483,11 +528,20 @@ int cs3_find_islands(int64_t n, const int32_t *Ap, const int32_t *Ai, int32_t *l
     SUB_HIP(hipMemcpy(ap.p, Ap, (size_t) (n + 1) * 4, hipMemcpyHostToDevice));
     if (nnz) SUB_HIP(hipMemcpy(ai.p, Ai, (size_t) nnz * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_label_init, dim3(blocks_for(n, 256)), dim3(256), 0, 0, lab.as<int>(), (int) n);
-    for (int64_t round = 0; round <= n; ++round) {                // root hooking + full compression: O(log n) rounds in practice
+    int unsym = 0;
+    SUB_HIP(hipMemset(chg.p, 0, 4));
+    hipLaunchKernelGGL(k_pattern_symmetric, dim3(blocks_for(n, 256)), dim3(256), 0, 0, ap.as<int>(), ai.as<int>(), (int) n, chg.as<int>());
+    SUB_HIP(hipMemcpy(&unsym, chg.p, 4, hipMemcpyDeviceToHost));
+    for (int64_t round = 0; round <= n; ++round) {
         int changed = 0;
         SUB_HIP(hipMemset(chg.p, 0, 4));
-        hipLaunchKernelGGL(k_label_hook, dim3(blocks_for(n, 256)), dim3(256), 0, 0, ap.as<int>(), ai.as<int>(), (int) n, lab.as<int>(), chg.as<int>());
-        hipLaunchKernelGGL(k_label_jump, dim3(blocks_for(n, 256)), dim3(256), 0, 0, lab.as<int>(), (int) n);
+        if (!unsym) {               // structurally symmetric: root hooking + full compression, O(log n) rounds in practice
+            hipLaunchKernelGGL(k_label_hook, dim3(blocks_for(n, 256)), dim3(256), 0, 0, ap.as<int>(), ai.as<int>(), (int) n, lab.as<int>(), chg.as<int>());
+            hipLaunchKernelGGL(k_label_jump, dim3(blocks_for(n, 256)), dim3(256), 0, 0, lab.as<int>(), (int) n);
+        } else {                    // directed reachability, the reference's exact semantics
+            hipLaunchKernelGGL(k_reach_hook, dim3(blocks_for(n, 256)), dim3(256), 0, 0, ap.as<int>(), ai.as<int>(), (int) n, lab.as<int>(), chg.as<int>());
+            hipLaunchKernelGGL(k_reach_jump, dim3(blocks_for(n, 256)), dim3(256), 0, 0, lab.as<int>(), (int) n, chg.as<int>());
+        }
         SUB_HIP(hipMemcpy(&changed, chg.p, 4, hipMemcpyDeviceToHost));
         if (!changed) break;
     }

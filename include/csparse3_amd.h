@@ -219,9 +219,10 @@ int cs3_csc_add(int64_t m, int64_t n, const int32_t *Ap, const int32_t *Ai, cons
 int cs3_csc_sub_matrix(int64_t n, const int32_t *Ap, const int32_t *Ai, const double *Ax,
                        const int32_t *rows, int64_t nrows, const int32_t *cols, int64_t ncols,
                        int32_t *Bp, int32_t *Bi, double *Bx, int64_t b_cap);
-/* label[i] = smallest node of the island (connected component of the pattern, either direction) that holds
- * node i: find_islands (csc_numba.py:744-808) lists islands by ascending smallest node, CscMat.islands
- * (csc.py:515-521) sorts each -- both follow from the labels. */
+/* label[i] = the node at which find_islands (csc_numba.py:744-808) opens the island that receives node i = the smallest
+ * node that reaches i along column -> row edges.  On a structurally symmetric pattern that is the smallest node of i's
+ * connected component; on an unsymmetric one it follows the reference's directed search exactly.  find_islands lists
+ * islands by ascending start node and CscMat.islands (csc.py:515-521) sorts each -- both follow from the labels. */
 int cs3_find_islands(int64_t n, const int32_t *Ap, const int32_t *Ai, int32_t *label);
 
 #ifdef __cplusplus

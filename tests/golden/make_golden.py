@@ -187,6 +187,25 @@ def main():
     out.update(isl_Ap=Ip, isl_Ai=Ii[:Ip[30]], isl_count=np.int64(len(isl)),
                isl_flat=np.concatenate(isl).astype(np.int32), isl_sizes=np.array([len(x) for x in isl], dtype=np.int32))
 
+    # islands where the pattern is NOT structurally symmetric and direction matters: find_islands follows column -> row
+    # edges only, so a node that reaches an island without being reachable from its start opens an island of its own.
+    # (a) hand-made: 3 -> 1 and 1 -> 0 exist, 0 -> anything does not: starts 0, 1, 2, 3, ... give {0}, {1}, {2, 5}, {3}, {4}
+    hp = {0: [0], 1: [1, 0], 2: [2, 5], 3: [3, 1], 4: [4, 0], 5: [5, 2]}          # column v -> its row indices
+    Hp = np.zeros(7, dtype=np.int32); Hi = []
+    for v in range(6):
+        Hi += hp[v]; Hp[v + 1] = len(Hi)
+    Hi = np.array(Hi, dtype=np.int32)
+    isl = [np.sort(np.array(list(x), dtype=np.int32)) for x in ref.find_islands(6, Hp, Hi)]
+    out.update(isd0_n=np.int64(6), isd0_Ap=Hp, isd0_Ai=Hi, isd0_flat=np.concatenate(isl).astype(np.int32),
+               isd0_sizes=np.array([len(x) for x in isl], dtype=np.int32))
+    # (b), (c) random directed patterns, rows unsorted, diagonal present or not
+    rng3 = np.random.default_rng(404)
+    for tag, (nn, dens) in {"isd1": (40, 0.03), "isd2": (90, 0.012)}.items():
+        Rp, Ri, _ = _random_csc(rng3, nn, nn, dens)
+        isl = [np.sort(np.array(list(x), dtype=np.int32)) for x in ref.find_islands(nn, Rp, Ri)]
+        out.update({tag + "_n": np.int64(nn), tag + "_Ap": Rp, tag + "_Ai": Ri, tag + "_flat": np.concatenate(isl).astype(np.int32),
+                    tag + "_sizes": np.array([len(x) for x in isl], dtype=np.int32)})
+
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, "with", len(out), "arrays")
 

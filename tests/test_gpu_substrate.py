@@ -79,6 +79,41 @@ def test_find_islands_matches_golden(gpu):
     assert np.array_equal(np.concatenate(isl), GOLD["isl_flat"])
 
 
+@pytest.mark.parametrize("tag", ["isd0", "isd1", "isd2"])
+def test_find_islands_on_unsymmetric_patterns_matches_the_reference(gpu, orc, tag):
+    """Direction matters: find_islands follows column -> row edges only (csc_numba.py:768-800), so these patterns give
+    other islands than the connected components.  Golden = the reference's own output; oracle and device both match."""
+    n = int(GOLD[tag + "_n"])
+    Ap, Ai = GOLD[tag + "_Ap"], GOLD[tag + "_Ai"]
+    want_flat, want_sizes = GOLD[tag + "_flat"], list(GOLD[tag + "_sizes"])
+    isl = gpu.find_islands(n, Ap, Ai)
+    assert [len(x) for x in isl] == want_sizes and np.array_equal(np.concatenate(isl), want_flat)
+    oi = orc.find_islands(n, Ap, Ai)
+    assert [len(x) for x in oi] == want_sizes and np.array_equal(np.concatenate(oi), want_flat)
+    # the weakly connected components are something else here
+    import scipy.sparse as sp
+    import scipy.sparse.csgraph as csg
+    G = sp.csc_matrix((np.ones(len(Ai)), Ai, Ap), shape=(n, n))
+    assert csg.connected_components(G, directed=False)[0] < len(want_sizes)
+
+
+def test_find_islands_directed_chain_converges_fast(gpu, orc):
+    """A one-directional chain 0 -> 1 -> ... -> n-1 plus a back-pointing tail: pointer doubling keeps the rounds
+    logarithmic; result = the reference's semantics (oracle restatement)."""
+    n = 20000
+    cols = np.arange(n - 1, dtype=np.int32)                  # column v holds row v + 1: edge v -> v + 1
+    Ap = np.concatenate([np.arange(n, dtype=np.int32), [n - 1]]).astype(np.int32)
+    Ai = (cols + 1).astype(np.int32)
+    isl = gpu.find_islands(n, Ap, Ai)
+    assert len(isl) == 1 and len(isl[0]) == n
+    # reversed edges: v -> v - 1: every node opens its own island except that 0 is reached by nobody smaller
+    Ap2 = np.concatenate([[0], np.arange(n, dtype=np.int32)]).astype(np.int32)
+    Ai2 = np.arange(n - 1, dtype=np.int32)
+    isl2 = gpu.find_islands(n, Ap2, Ai2)
+    oi2 = orc.find_islands(n, Ap2, Ai2)
+    assert [len(x) for x in isl2] == [len(x) for x in oi2] and np.array_equal(np.concatenate(isl2), np.concatenate(oi2))
+
+
 def _random_csc(rng, m, n, per_col, dup=False):
     cols = np.repeat(np.arange(n), per_col)
     rows = rng.integers(0, m, size=len(cols))

@@ -246,3 +246,13 @@ def test_find_islands_matches_reference(orc):
     isl = orc.find_islands(30, GOLD["isl_Ap"], GOLD["isl_Ai"])
     assert len(isl) == int(GOLD["isl_count"]) and [len(x) for x in isl] == list(GOLD["isl_sizes"])
     assert np.array_equal(np.concatenate(isl), GOLD["isl_flat"])
+
+
+@pytest.mark.parametrize("tag", ["isd0", "isd1", "isd2"])
+def test_find_islands_unsymmetric_patterns_match_reference(orc, tag):
+    """find_islands follows column -> row edges only (csc_numba.py:768-800): on these patterns the islands are not the
+    connected components.  The oracle reproduces the reference's own output (tests/golden/make_golden.py)."""
+    n = int(GOLD[tag + "_n"])
+    isl = orc.find_islands(n, GOLD[tag + "_Ap"], GOLD[tag + "_Ai"])
+    assert [len(x) for x in isl] == list(GOLD[tag + "_sizes"])
+    assert np.array_equal(np.concatenate(isl), GOLD[tag + "_flat"])

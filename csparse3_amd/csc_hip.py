@@ -107,6 +107,8 @@ def lib():
             f.argtypes = [vp, _f64p, I64]
         for f in (L.cs3_solve_dev, L.cs3_lsolve_dev, L.cs3_usolve_dev):
             f.argtypes = [vp, vp, I64, vp]
+        L.cs3_residual_dev.argtypes = [vp, vp, vp, vp, vp, I64, vp]
+        L.cs3_refine_dev.argtypes = [vp, vp, vp, vp, I64, I64, C.POINTER(C.c_double), vp]
         L.cs3_export_factor_dev.argtypes = [vp, vp, vp]
         L.cs3_import_factor_dev.argtypes = [vp, vp, vp]
         L.cs3_get_factors.argtypes = [vp, I64, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p]
@@ -307,6 +309,18 @@ class Factorization:
 
     def usolve_dev(self, x_ptr, k=1, stream=0):
         _check(lib().cs3_usolve_dev(self._h, C.c_void_p(x_ptr), k, C.c_void_p(stream)))
+
+    def residual_dev(self, ax_ptr, b_ptr, x_ptr, r_ptr, k=1, stream=0):
+        """R = B - A X on resident data (A's values at ax_ptr, the analysed pattern); csc_mat_vec_ff's summation order."""
+        _check(lib().cs3_residual_dev(self._h, C.c_void_p(ax_ptr), C.c_void_p(b_ptr), C.c_void_p(x_ptr), C.c_void_p(r_ptr), k,
+                                      C.c_void_p(stream)))
+
+    def refine_dev(self, ax_ptr, b_ptr, x_ptr, k=1, steps=1, stream=0, want_correction=True):
+        """`steps` rounds of x += A \\ (b - A x) with the factors at hand; returns max |dx| of the last round."""
+        out = C.c_double(0.0)
+        _check(lib().cs3_refine_dev(self._h, C.c_void_p(ax_ptr), C.c_void_p(b_ptr), C.c_void_p(x_ptr), k, steps,
+                                    C.byref(out) if want_correction else None, C.c_void_p(stream)))
+        return float(out.value)
 
     def export_factor_dev(self, dst_ptr, stream=0):
         """Copy the factor panels (info.factor_bytes per matrix) into an HBM buffer."""

@@ -49,6 +49,12 @@ struct cs3_handle_s {
     double *d_lx = nullptr, *d_ux = nullptr;
     long long fail_col = -1;
     bool inverses_valid = false;      // inverted diagonal blocks (many-RHS GEMM sweeps) match the current factors
+    // residual / refinement: the analysed pattern in row view (built on first use), a work array, a result word
+    std::vector<i32> Ap_host, Ai_host;
+    int *d_rp = nullptr, *d_rj = nullptr, *d_rmap = nullptr;
+    double *d_res = nullptr;
+    long long res_cap = 0;
+    unsigned long long *d_maxbits = nullptr;
 };
 
 namespace {
@@ -85,7 +91,9 @@ void release_device(cs3_handle h)
                      (void **) &D.q, (void **) &D.ila_pairs, (void **) &D.inv_tasks, (void **) &D.dinv, (void **) &D.gv,
                      (void **) &D.ax, (void **) &D.pool, (void **) &D.dbuf, (void **) &D.tbuf, (void **) &D.bigv,
                      (void **) &D.cv, (void **) &D.xp, (void **) &D.status, (void **) &h->d_lmap, (void **) &h->d_umap,
-                     (void **) &h->d_lx, (void **) &h->d_ux};
+                     (void **) &h->d_lx, (void **) &h->d_ux, (void **) &h->d_rp, (void **) &h->d_rj, (void **) &h->d_rmap,
+                     (void **) &h->d_res, (void **) &h->d_maxbits};
+    h->res_cap = 0;
     for (void **p : ptrs) if (*p) { (void) hipFree(*p); *p = nullptr; }
     D.nrhs_cap = 0;
     h->on_device = false;
@@ -482,6 +490,8 @@ int cs3_analyze(int64_t kind, int64_t order, int64_t n, const int32_t *Ap, const
         h = new cs3_handle_s();
         h->batch = batch;
         analyze((int) kind, (int) order, n, Ap, Ai, q_given, h->S, batch);
+        h->Ap_host.assign(Ap, Ap + n + 1);
+        h->Ai_host.assign(Ai, Ai + (n > 0 ? Ap[n] : 0));
     } catch (const std::bad_alloc &) {
         delete h; set_error("cs3_analyze: out of memory"); return CS3_ERR_ALLOC;
     } catch (const std::exception &e) {
@@ -851,6 +861,70 @@ int cs3_csc_stack_4_by_4(int64_t am, int64_t an, const int32_t *Ai, const int32_
     if (e == hipSuccess && nnz) e = hipMemcpy(Px, d_px, (size_t) nnz * sizeof(double), hipMemcpyDeviceToHost);
     cleanup();
     CS3_HIP(e);
+    return CS3_OK;
+}
+
+// ---- residual and iterative refinement on resident data ---------------------------------
+static int ensure_row_view(cs3_handle h, long long k)
+{
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    const Symbolic &S = h->S;
+    if (!h->d_rp) {
+        const i64 n = S.n, nnz = S.nnzA;
+        std::vector<int> Rp(n + 1, 0), Rj(nnz), Rmap(nnz);
+        const i32 *Ap = h->Ap_host.data(), *Ai = h->Ai_host.data();
+        for (i64 p = 0; p < nnz; ++p) ++Rp[Ai[p] + 1];
+        for (i64 i = 0; i < n; ++i) Rp[i + 1] += Rp[i];
+        std::vector<int> fill(Rp.begin(), Rp.end() - 1);
+        for (i64 j = 0; j < n; ++j)                      // ascending column inside every row: csc_mat_vec_ff's summation order
+            for (i64 p = Ap[j]; p < Ap[j + 1]; ++p) { const int q = fill[Ai[p]]++; Rj[q] = (int) j; Rmap[q] = (int) p; }
+        if ((rc = upload(&h->d_rp, Rp)) || (rc = upload(&h->d_rj, Rj)) || (rc = upload(&h->d_rmap, Rmap))) return rc;
+        CS3_HIP(hipMalloc((void **) &h->d_maxbits, sizeof(unsigned long long)));
+    }
+    const long long need = h->batch * S.n * k;
+    if (need > h->res_cap) {
+        CS3_HIP(hipDeviceSynchronize());
+        if (h->d_res) (void) hipFree(h->d_res);
+        h->d_res = nullptr; h->res_cap = 0;
+        CS3_HIP(hipMalloc((void **) &h->d_res, std::max<size_t>(8, (size_t) need * sizeof(double))));
+        h->res_cap = need;
+    }
+    return CS3_OK;
+}
+
+int cs3_residual_dev(cs3_handle h, const double *Ax_dev, const double *B_dev, const double *X_dev, double *R_dev, int64_t k, void *stream)
+{
+    int rc = guard(h); if (rc) return rc;
+    if (!Ax_dev || !B_dev || !X_dev || !R_dev || k < 1 || k > INT_MAX) { set_error("cs3_residual_dev: bad argument"); return CS3_ERR_ARG; }
+    if ((rc = ensure_row_view(h, 0))) return rc;
+    CS3_HIP(launch_residual(h->d_rp, h->d_rj, h->d_rmap, Ax_dev, X_dev, B_dev, R_dev, h->S.n, (int) k, h->S.nnzA, h->batch, (hipStream_t) stream));
+    return CS3_OK;
+}
+
+int cs3_refine_dev(cs3_handle h, const double *Ax_dev, const double *B_dev, double *X_dev, int64_t k, int64_t steps,
+                   double *last_correction, void *stream)
+{
+    int rc = guard(h); if (rc) return rc;
+    if (!Ax_dev || !B_dev || !X_dev || k < 1 || k > INT_MAX || steps < 0) { set_error("cs3_refine_dev: bad argument"); return CS3_ERR_ARG; }
+    if (!h->factored) { set_error("cs3_refine_dev: refinement needs a factorisation"); return CS3_ERR_STATE; }
+    if ((rc = ensure_row_view(h, k))) return rc;
+    hipStream_t st = (hipStream_t) stream;
+    const long long total = h->batch * h->S.n * k;
+    for (int64_t s = 0; s < steps; ++s) {
+        CS3_HIP(launch_residual(h->d_rp, h->d_rj, h->d_rmap, Ax_dev, X_dev, B_dev, h->d_res, h->S.n, (int) k, h->S.nnzA, h->batch, st));
+        if ((rc = run_solve(h, h->d_res, k, 0, st))) return rc;           // d = A \ r with the factors at hand
+        const bool want = last_correction && s + 1 == steps;
+        if (want) CS3_HIP(hipMemsetAsync(h->d_maxbits, 0, sizeof(unsigned long long), st));
+        CS3_HIP(launch_axpy_max(X_dev, h->d_res, total, want ? h->d_maxbits : nullptr, st));      // x += d
+        if (want) {
+            unsigned long long bits = 0;
+            CS3_HIP(hipMemcpyAsync(&bits, h->d_maxbits, sizeof(bits), hipMemcpyDeviceToHost, st));
+            CS3_HIP(hipStreamSynchronize(st));
+            std::memcpy(last_correction, &bits, sizeof(double));
+        }
+    }
+    if (steps == 0 && last_correction) *last_correction = 0.0;
     return CS3_OK;
 }
 

@@ -133,6 +133,9 @@ hipError_t launch_stack_4_by_4(int an, int bn, int am, int bm, const int *Ap, co
                                int *Pp, int *Pi, double *Px, int *map, hipStream_t st);
 hipError_t launch_restack_values(long long nnz, const int *map, long long na, long long nb, long long nc, const double *Ax,
                                  const double *Bx, const double *Cx, const double *Dx, double *Px, hipStream_t st);
+hipError_t launch_residual(const int *Rp, const int *Rj, const int *Rmap, const double *Ax, const double *X, const double *B,
+                           double *R, long long n, int nrhs, long long nnz_a, long long batch, hipStream_t st);
+hipError_t launch_axpy_max(double *X, const double *D, long long total, unsigned long long *maxbits, hipStream_t st);
 hipError_t launch_matvec_rows(const int *Rp, const int *Rj, const double *Rx, const double *X, double *Y,
                               long long m, int nrhs, hipStream_t st);
 

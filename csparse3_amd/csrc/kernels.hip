@@ -2791,6 +2791,63 @@ k_matvec_rows(const int *__restrict__ Rp, const int *__restrict__ Rj,
     }
 }
 
+// R = B - A X with A in the CSR-ordered view of the handle's CSC arrays (Rmap: CSR entry -> entry of Ax): the product
+// row is summed as csc_mat_vec_ff does (ascending column, separate multiply and add roundings, csc_numba.py:309-328),
+// then subtracted from b.  One thread per (row, right-hand side); fixed order, reproducible.
+__global__ void __launch_bounds__(256)
+k_residual_rows(const int *__restrict__ Rp, const int *__restrict__ Rj, const int *__restrict__ Rmap,
+                const double *__restrict__ Ax_all, const double *__restrict__ X_all, const double *__restrict__ B_all,
+                double *__restrict__ R_all, long long n, int nrhs, long long nnz_a)
+{
+    const double *Ax = Ax_all + (long long) blockIdx.y * nnz_a;
+    const double *X = X_all + (long long) blockIdx.y * n * nrhs;
+    const double *B = B_all + (long long) blockIdx.y * n * nrhs;
+    double *R = R_all + (long long) blockIdx.y * n * nrhs;
+    const long long total = n * nrhs;
+    for (long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long) gridDim.x * blockDim.x) {
+        const long long i = e / nrhs;
+        const int t = (int) (e - i * nrhs);
+        double y = 0.0;
+        for (int p = Rp[i]; p < Rp[i + 1]; ++p) {
+#pragma clang fp contract(off)
+            const double prod = Ax[Rmap[p]] * X[(long long) Rj[p] * nrhs + t];
+            y = y + prod;
+        }
+        R[e] = B[e] - y;
+    }
+}
+
+// X += D; out[0] = max |D| over everything (atomicMax on the bit pattern of a non-negative double is exact)
+__global__ void __launch_bounds__(256)
+k_axpy_max(double *__restrict__ X, const double *__restrict__ D, long long total, unsigned long long *maxbits)
+{
+    double m = 0.0;
+    for (long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long) gridDim.x * blockDim.x) {
+        const double dv = D[e];
+        if (X) X[e] += dv;
+        const double a = fabs(dv);
+        m = (a > m || a != a) ? a : m;
+    }
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(m, off); m = (o > m || o != o) ? o : m; }
+    if ((threadIdx.x & 63) == 0 && maxbits) atomicMax(maxbits, (unsigned long long) __double_as_longlong(m));
+}
+
+hipError_t launch_residual(const int *Rp, const int *Rj, const int *Rmap, const double *Ax, const double *X, const double *B,
+                           double *R, long long n, int nrhs, long long nnz_a, long long batch, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    dim3 grid((unsigned) std::min<long long>((n * nrhs + 255) / 256, 4096), (unsigned) batch);
+    hipLaunchKernelGGL(k_residual_rows, grid, dim3(256), 0, st, Rp, Rj, Rmap, Ax, X, B, R, n, nrhs, nnz_a);
+    return hipGetLastError();
+}
+
+hipError_t launch_axpy_max(double *X, const double *D, long long total, unsigned long long *maxbits, hipStream_t st)
+{
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_axpy_max, dim3((unsigned) std::min<long long>((total + 255) / 256, 2048)), dim3(256), 0, st, X, D, total, maxbits);
+    return hipGetLastError();
+}
+
 // 2 x 2 block stacking [[A, B], [C, D]] in CSC (power-flow Jacobian assembly), the layout of
 // csc_stack_4_by_4_ff (csc_numba.py:640-720): output column j < an is A(:,j) followed by C(:,j)
 // with rows shifted by am; column an + j is B(:,j) followed by D(:,j) shifted by bm.  Column

@@ -130,6 +130,18 @@ int cs3_solve_dev(cs3_handle h, double *X_dev, int64_t k, void *stream);
 int cs3_lsolve_dev(cs3_handle h, double *X_dev, int64_t k, void *stream);
 int cs3_usolve_dev(cs3_handle h, double *X_dev, int64_t k, void *stream);
 
+/* ---- residual and iterative refinement on resident data ----
+ * R = B - A X with the handle's analysed pattern and the values Ax_dev [batch][nnz]; X, B, R [batch][n, k] row-major.
+ * Every row of A X is summed as csc_mat_vec_ff sums it (csc_numba.py:309-328: ascending column, product rounded before
+ * the add), so results are reproducible and A X equals the reference's matvec bit for bit. */
+int cs3_residual_dev(cs3_handle h, const double *Ax_dev, const double *B_dev, const double *X_dev, double *R_dev,
+                     int64_t k, void *stream);
+/* `steps` rounds of  x += A \ (b - A x)  with the factors the handle holds (e.g. factors of an earlier Newton iterate
+ * refining the solution for the current values Ax_dev).  last_correction (optional): max |dx| of the last round
+ * (reading it synchronises the stream). */
+int cs3_refine_dev(cs3_handle h, const double *Ax_dev, const double *B_dev, double *X_dev, int64_t k, int64_t steps,
+                   double *last_correction, void *stream);
+
 /* ---- factors back to the host in CSparse's CSC form ---------------------
  * L: diagonal FIRST in each column (unit for LU); U: diagonal LAST; row
  * indices sorted otherwise.  Sizes from cs3_info.nnz_l / nnz_u.  NumPy-style

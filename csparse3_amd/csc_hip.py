@@ -19,7 +19,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcsparse3_hip.so")
+LIB_PATH = os.environ.get("CS3_LIB_PATH") or os.path.join(_HERE, "libcsparse3_hip.so")   # (override: sanitizer builds, tools/asan_host.sh)
 
 CS3_LU, CS3_CHOLESKY = 0, 1
 ORDER_NATURAL, ORDER_AMD, ORDER_GIVEN = 0, 1, 2

@@ -20,8 +20,10 @@ struct FrontDesc {
     int parent;
 };
 
-// Doubles allocated past the end of the factor pool: the lane = right-hand-side sweeps read whole
-// 32-row columns of a panel whatever its height.
+// Doubles allocated past the end of the factor pool.  Nothing relies on them: every load in kernels.hip goes through
+// load_if or an explicit bound (audited in round 2: all base pointers are front buffers, the two call sites whose base
+// depends on a right-hand-side slot clamp the slot, the lane = right-hand-side sweeps predicate i < r && k < w).  Kept
+// as a margin, not as part of any kernel's contract.
 constexpr size_t POOL_SLACK = 2048;
 
 // Fused permutations (many right-hand sides): the forward sweep takes row k of the permuted right-hand sides from

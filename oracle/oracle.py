@@ -69,6 +69,8 @@ def lib():
     if _lib is None:
         if _native:
             _lib = C.CDLL(os.path.join(_HERE, "_native", "liboracle_native.so"))
+        elif os.environ.get("ORC_LIB_PATH"):                  # sanitizer build of the same source (tools/asan_host.sh)
+            _lib = C.CDLL(os.environ["ORC_LIB_PATH"])
         else:
             build()
             _lib = C.CDLL(_LIB_PATH)

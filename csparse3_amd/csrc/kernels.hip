@@ -3461,6 +3461,7 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
     static const bool overlap = !(getenv("CS3_NO_OVERLAP") && getenv("CS3_NO_OVERLAP")[0] == '1');
     for (int l = 0; overlap && l + 1 < nlevels; ++l)
         if (tail[l + 1] >= head[l + 1]) fork_level = l;
+    if (const char *fl = getenv("CS3_FORK_LEVEL")) { const int v = atoi(fl); if (overlap && v >= 0 && v + 1 < nlevels) fork_level = v; }
 
     auto sweep = [&](int lo, int hi, hipStream_t s) -> hipError_t {      // forward sweep of levels lo..hi
         for (const LaunchGroup &g : sgroups) {
@@ -3485,7 +3486,8 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
         if (nf != 1 || ns != 1 || rootf->cls != FC_BIG || roots->cls != SK_BIG || rootf->count != roots->count)
             rootf = roots = nullptr;
     }
-    hipEvent_t swept = nullptr;
+    hipEvent_t swept = nullptr, ready_deferred = nullptr;
+    static const bool defer_sweep = getenv("CS3_DEFER_SWEEP") && getenv("CS3_DEFER_SWEEP")[0] == '1';
     int root_rest = 0;                             // first chunk of the root's sweep that is still to do after the join
     for (size_t f0 = 0; f0 < fgroups.size(); ) {
         const int level = fgroups[f0].level;
@@ -3495,6 +3497,10 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
             const BigSweepPlan pl = big_sweep_plan(D, *roots, nrhs);
             const int nblk = big_group_blocks(*rootf), cwb = pl.cw / BIG_NB;
             if ((e = launch_big_gather(D, *rootf, st)) != hipSuccess) return e;
+            if (ready_deferred) {                  // experiment: the side branch is captured AFTER the root chain has begun
+                if ((e = hipStreamWaitEvent(fj.aux, ready_deferred, 0)) != hipSuccess) return e;
+                if ((e = sweep(0, fork_level, fj.aux)) != hipSuccess) return e;
+            }
             if ((e = launch_fwd_big_pre(D, *roots, X, nrhs, fj.aux)) != hipSuccess) return e;
             // ONE release (every cross-stream edge costs the block chain about 10 us): the first k chunks go to
             // fj.aux after block launch k * cwb, k the largest count that the remaining launches still cover;
@@ -3543,10 +3549,13 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
             hipEvent_t ready;                      // panels of levels 0..fork_level are final
             if ((e = fj.event(&ready)) != hipSuccess) return e;
             if ((e = hipEventRecord(ready, st)) != hipSuccess) return e;
-            if ((e = hipStreamWaitEvent(fj.aux, ready, 0)) != hipSuccess) return e;
-            if ((e = sweep(0, fork_level, fj.aux)) != hipSuccess) return e;
-            if ((e = fj.event(&swept)) != hipSuccess) return e;
-            if ((e = hipEventRecord(swept, fj.aux)) != hipSuccess) return e;
+            if (defer_sweep && rootf) { ready_deferred = ready; }
+            else {
+                if ((e = hipStreamWaitEvent(fj.aux, ready, 0)) != hipSuccess) return e;
+                if ((e = sweep(0, fork_level, fj.aux)) != hipSuccess) return e;
+                if ((e = fj.event(&swept)) != hipSuccess) return e;
+                if ((e = hipEventRecord(swept, fj.aux)) != hipSuccess) return e;
+            }
         }
         f0 = f1;
     }

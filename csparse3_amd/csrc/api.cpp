@@ -88,7 +88,7 @@ void release_device(cs3_handle h)
     h->fj.destroy();
     void **ptrs[] = {(void **) &D.fdesc, (void **) &D.st_idx, (void **) &D.asm_src, (void **) &D.asm_tgt, (void **) &D.long_src,
                      (void **) &D.sdesc, (void **) &D.fasm_src, (void **) &D.fasm_tgt, (void **) &D.flong_src, (void **) &D.rl_pairs,
-                     (void **) &D.q, (void **) &D.ila_pairs, (void **) &D.inv_tasks, (void **) &D.dinv, (void **) &D.gv,
+                     (void **) &D.sl_src,                     (void **) &D.q, (void **) &D.ila_pairs, (void **) &D.inv_tasks, (void **) &D.dinv, (void **) &D.gv,
                      (void **) &D.ax, (void **) &D.pool, (void **) &D.dbuf, (void **) &D.tbuf, (void **) &D.bigv,
                      (void **) &D.cv, (void **) &D.xp, (void **) &D.status, (void **) &h->d_lmap, (void **) &h->d_umap,
                      (void **) &h->d_lx, (void **) &h->d_ux, (void **) &h->d_rp, (void **) &h->d_rj, (void **) &h->d_rmap,
@@ -155,6 +155,7 @@ int ensure_device_impl(cs3_handle h)
         f.bv = S.bv_off[s];
         f.gv = S.gv_off[s]; f.dinv = S.dinv_off[s];
         f.rl_begin = S.rl_ptr[s]; f.rl_count = (int) (S.rl_ptr[s + 1] - S.rl_ptr[s]);
+        if (S.sn_class[s] != FC_IL) { f.rl_begin = S.sl_ptr[s]; f.rl_count = S.sl_rounds[s]; }
         f.c0 = S.sn_ptr[s];
         f.r = (int) (S.st_ptr[s + 1] - S.st_ptr[s]);
         f.w = S.sn_ptr[s + 1] - S.sn_ptr[s];
@@ -167,6 +168,7 @@ int ensure_device_impl(cs3_handle h)
     if ((rc = upload(&D.fasm_tgt, S.fasm_tgt))) return rc;
     if ((rc = upload(&D.flong_src, S.flong_src))) return rc;
     if ((rc = upload(&D.rl_pairs, S.rl_pairs))) return rc;
+    if ((rc = upload(&D.sl_src, S.sl_src))) return rc;
     if ((rc = upload(&D.fdesc, fdesc))) return rc;
     if ((rc = upload(&D.st_idx, S.st_idx))) return rc;
     if ((rc = upload(&D.asm_src, S.asm_src))) return rc;

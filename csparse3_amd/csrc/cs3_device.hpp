@@ -39,8 +39,9 @@ struct SolveDesc {
     long long lpan, upan, cv, st, fasm_begin;
     long long bv;                 // SK_BIG fronts: offset of the full front vector in bigv
     long long gv, dinv;           // fronts of order > 64: first row in the gv buffer, offset of the inverted diagonal blocks
-    long long rl_begin;           // SK_SMALL fronts: first (target, source) pair of the children's additions
-    int rl_count;                 //   pairs, a multiple of 16
+    long long rl_begin;           // what the children add to the front vector: SK_IL fronts, first (target, source) pair in rl_pairs
+    int rl_count;                 //   and the number of pairs (a multiple of 16); other fronts, first entry in sl_src and the
+                                  //   number of slot rounds (a round = 16 ceil(r / 16) sources, -1 = none)
     int fasm_count;
     int c0, r, w;
     int u_sk, u_sj;               // U(k, j) = pool[upan + k*u_sk + (j-w)*u_sj]
@@ -59,7 +60,7 @@ struct DeviceFactor {
     int *asm_src = nullptr, *asm_tgt = nullptr, *long_src = nullptr;
     SolveDesc *sdesc = nullptr;
     int *fasm_src = nullptr, *fasm_tgt = nullptr, *flong_src = nullptr;
-    int *rl_pairs = nullptr;
+    int *rl_pairs = nullptr, *sl_src = nullptr;
     int *q = nullptr;             // [n] pivot order
     double *ax = nullptr;         // [batch][nnz_a] values of A (stable address for the graph)
     double *pool = nullptr;       // the allocation: [groups][il_len][64] interleaved block, then [batch][pm_stride]

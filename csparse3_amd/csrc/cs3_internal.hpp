@@ -37,7 +37,7 @@ enum FrontClass : int { FC_R16 = 0, FC_R32 = 1, FC_R64 = 2, FC_LDS = 3, FC_BIG =
 // right-hand sides (adjacent in the schedule, launched as one group); with many right-hand sides
 // SK_SMALL fronts run lane = right-hand side.
 enum SolveKind : int {
-    SK_SMALL = 0,      // r <= 64
+    SK_SMALL = 0,      // r <= 32 (CS3_RHS_LANES_RMAX, at most 64)
     SK_WAVE = 1,       // r <= 128, w <= 64
     SK_BLOCK = 2,      // one workgroup per front
     SK_BIG = 3,        // w > 64, r > 136: one launch per 64-column chunk, many workgroups
@@ -103,8 +103,10 @@ struct Symbolic {
     std::vector<i32> fasm_src, fasm_tgt, flong_src;
     // solve schedule: supernodes by (level, kind), see SolveKind
     std::vector<i32> ssched;
-    std::vector<i64> rl_ptr;                  // SK_SMALL fronts: children's additions as (target, source) pairs
+    std::vector<i64> rl_ptr;                  // SK_IL fronts: children's additions as (target, source) pairs
     std::vector<i32> rl_pairs;                //   sorted by target, padded to multiples of 16 with target -1
+    std::vector<i64> sl_ptr;                  // SK_SMALL fronts: the same additions as slot rounds (symbolic.cpp, 10b)
+    std::vector<i32> sl_rounds, sl_src;
     std::vector<i64> bv_off;                  // kind-2 fronts: offset of their full front vector in the bigv buffer
     i64 bv_size = 0;
     // Many right-hand sides: fronts of order > 64 sweep as GEMMs (k_gemm_fwd / k_gemm_bwd).  Their front vectors

@@ -79,6 +79,7 @@ __device__ __forceinline__ double *il_lane_base(const IlView &il, long long m)
 constexpr int ASM_DUMMY_T = 0x3fffffff;
 constexpr int ASM_LONG_T = 0x40000000;
 constexpr int GATHER_UNROLL = 4;
+constexpr int GATHER_UNROLL_WG = 8;             // one workgroup of 8 waves per front (fronts of order > 64): 4096 entries per pass
 
 // Fetch(s) returns the address of source s (an unconditional load keeps loads in flight).
 template <class Fetch>
@@ -113,31 +114,32 @@ __device__ __forceinline__ bool run_totals(int t, double &v)
     return is_last;
 }
 
-// Store(t, v) is called once per assembled entry.
-template <class Fetch, class Store>
-__device__ __forceinline__ void gather_front(long long asm_begin, int nchunks, int chunk_first, int chunk_stride,
+// Store(t, v) is called once per assembled entry.  Wave `wave` of `nwaves` takes the chunks wave, wave + nwaves, ...,
+// U of them per pass: the index loads of a pass go out together, then its value loads (two round trips per pass).
+template <int U = GATHER_UNROLL, class Fetch, class Store>
+__device__ __forceinline__ void gather_front(long long asm_begin, int nchunks, int wave, int nwaves,
                                              const int *__restrict__ asm_src, const int *__restrict__ asm_tgt,
                                              const int *__restrict__ long_src, Fetch fetch, Store store)
 {
     const int lane = threadIdx.x & 63;
-    for (int c0 = chunk_first; c0 < nchunks; c0 += chunk_stride) {
-        int t[GATHER_UNROLL], s[GATHER_UNROLL];
-        double v[GATHER_UNROLL];
+    for (int c0 = wave; c0 < nchunks; c0 += nwaves * U) {
+        int t[U], s[U];
+        double v[U];
 #pragma unroll
-        for (int u = 0; u < GATHER_UNROLL; ++u) {
-            const bool valid = c0 + u < nchunks;
-            const long long idx = asm_begin + (long long) (valid ? c0 + u : c0) * 64 + lane;
+        for (int u = 0; u < U; ++u) {
+            const bool valid = c0 + u * nwaves < nchunks;
+            const long long idx = asm_begin + (long long) (valid ? c0 + u * nwaves : c0) * 64 + lane;
             const int tl = asm_tgt[idx], sl = asm_src[idx];
             t[u] = valid ? tl : ASM_DUMMY_T;
             s[u] = valid ? sl : 0;
         }
 #pragma unroll
-        for (int u = 0; u < GATHER_UNROLL; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int s_next = __shfl_down(s[u], 1);
             v[u] = gather_value(t[u], s[u], s_next, long_src, fetch);
         }
 #pragma unroll
-        for (int u = 0; u < GATHER_UNROLL; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int tt = t[u] & ~ASM_LONG_T;
             const bool is_last = run_totals(tt, v[u]);
             if (is_last && tt != ASM_DUMMY_T) store(tt, v[u]);
@@ -222,7 +224,7 @@ front_lds_body(const FrontDesc &d, int first, double *F,
     for (int i = tid; i < r * ld; i += THREADS) F[i] = 0.0;
     __syncthreads();
     CS3_STAMP(1);
-    gather_front(d.asm_begin, d.asm_count >> 6, (tid >> 6) * GATHER_UNROLL, (THREADS / 64) * GATHER_UNROLL,
+    gather_front(d.asm_begin, d.asm_count >> 6, tid >> 6, THREADS / 64,
                  asm_src, asm_tgt, long_src,
                  [&](int q) -> const double * { return (q >= 0) ? ((q < il.len) ? pil + (long long) q * 64 : pool + q) : ax + ~q; },
                  [&](int t, double v) { F[t] = v; });
@@ -348,7 +350,7 @@ front_wave_body(const FrontDesc &d, int first, double *F,
     for (int i = threadIdx.x; i < r * ld; i += blockDim.x) F[i] = 0.0;
     __syncthreads();
     CS3_STAMP(1);
-    gather_front(d.asm_begin, d.asm_count >> 6, (threadIdx.x >> 6) * GATHER_UNROLL, nwaves * GATHER_UNROLL,
+    gather_front(d.asm_begin, d.asm_count >> 6, threadIdx.x >> 6, nwaves,
                  asm_src, asm_tgt, long_src,
                  [&](int q) -> const double * { return (q >= 0) ? ((q < il.len) ? pil + (long long) q * 64 : pool + q) : ax + ~q; },
                  [&](int t, double v) { F[t] = v; });
@@ -529,7 +531,7 @@ k_big_gather(const FrontDesc *__restrict__ fdesc, int first,
     const double *ax = ax_all + (long long) blockIdx.y * nnz_a;
     double *pool = pool_all + (long long) blockIdx.y * pool_stride;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    gather_front(d.asm_begin, d.asm_count >> 6, wave * GATHER_UNROLL, gridDim.x * 4 * GATHER_UNROLL,
+    gather_front(d.asm_begin, d.asm_count >> 6, wave, gridDim.x * 4,
                  asm_src, asm_tgt, long_src,
                  [&](int q) -> const double * { return (q >= 0) ? ((q < il.len) ? pil + (long long) q * 64 : pool + q) : ax + ~q; },
                  [&](int t, double v) { pool[t] = v; });
@@ -612,7 +614,7 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
     for (int i = tid; i < r * ld + 1; i += 512) F[i] = 0.0;
     __syncthreads();
     CS3_STAMP(1);
-    gather_front(d.asm_begin, d.asm_count >> 6, wv * GATHER_UNROLL, 8 * GATHER_UNROLL, asm_src, asm_tgt, long_src,
+    gather_front<GATHER_UNROLL_WG>(d.asm_begin, d.asm_count >> 6, wv, 8, asm_src, asm_tgt, long_src,
                  [&](int q) -> const double * { return (q >= 0) ? ((q < il.len) ? pil + (long long) q * 64 : pool + q) : ax + ~q; },
                  [&](int t, double v) { F[t] = v; });
     __syncthreads();
@@ -777,7 +779,7 @@ k_front_wg(const FrontDesc *__restrict__ fdesc, int first,
     for (long long e = tid; e < (long long) r * r; e += 512) F[e] = 0.0;
     __syncthreads();
     CS3_WSTAMP(0);
-    gather_front(d.asm_begin, d.asm_count >> 6, wv * GATHER_UNROLL, 8 * GATHER_UNROLL, asm_src, asm_tgt, long_src,
+    gather_front<GATHER_UNROLL_WG>(d.asm_begin, d.asm_count >> 6, wv, 8, asm_src, asm_tgt, long_src,
                  [&](int q) -> const double * { return (q >= 0) ? ((q < il.len) ? pil + (long long) q * 64 : pool + q) : ax + ~q; },
                  [&](int t, double v) { pool[t] = v; });
     __syncthreads();
@@ -1282,14 +1284,17 @@ k_bwd_wave(const SolveDesc *__restrict__ sd, int first, int count, const int *__
 // row of the tile is one coalesced 512-byte access and every lane runs the same scalar recurrence
 // on its own column: no cross-lane traffic in the data.  (The lane = row kernels above serve 8
 // right-hand sides per pass.)
-//   * the front vector sits in statically indexed registers; only the assembly, whose targets are
-//     data, goes through LDS, where each lane touches nothing but its own column;
+//   * the front vector sits in statically indexed registers, the assembly included: the children's
+//     additions come as SLOT ROUNDS (round j = the j-th source of every row, -1 where a row has fewer),
+//     so the target of an addition is a compile-time register and only the source address is data
+//     (round 2; the first version kept the vector in LDS for the assembly, which capped the occupancy
+//     at 10 waves per CU and paid an LDS read-modify-write per row);
 //   * the panel is the same for every lane.  It is fetched ONCE, zero-padded, by one round of
 //     coalesced vector loads into registers (PanelRegs) and its entries reach the FMAs by v_readlane.  Scalar loads would feed the FMAs
 //     for free, but a lone wave then waits out ~60 scalar-cache misses per front (measured: 30 us
 //     per launch whatever the level's size);
-//   * the children's additions come as (target, source) pairs sorted by target: pairs are loaded 64
-//     at a time as vectors, rows 16 at a time with the next 16 already in flight.
+//   * lane t loads the slot indices of row t (one coalesced load per round), the sources are read 16
+//     rows at a time (16 loads in flight); rounds beyond a row's last source read nothing.
 // A matrix M(i, t), i, t < RMAX, the same for every lane, held in registers: RMAX <= 32 packs two
 // columns per register (lane = i + 32 (t & 1), register = t / 2), RMAX = 64 one (lane = i).
 template <int RMAX> struct PanelRegs {
@@ -1305,12 +1310,11 @@ template <int RMAX> struct PanelRegs {
 };
 
 template <int KIND, int RMAX>
-__global__ void __launch_bounds__(64, (RMAX <= 32) ? 2 : 1)
-k_fwd_rhs(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ rl,
+__global__ void __launch_bounds__(64, (RMAX <= 16) ? 4 : (RMAX <= 32) ? 2 : 1)
+k_fwd_rhs(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ slots,
           const double *__restrict__ pool_all, double *cv_all, double *X_all,
           int nrhs, long long pool_stride, long long cv_stride, long long x_stride, XMap xm)
 {
-    __shared__ double vl[RMAX * 64];
     const SolveDesc d = sd[first + blockIdx.x];
     const int lane = threadIdx.x;
     // fused permutation: row k of the right-hand sides in pivot order is row q[k] of the caller's array
@@ -1324,6 +1328,13 @@ k_fwd_rhs(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ r
     double *X = X_all + (long long) blockIdx.y * x_stride;
     const int r = d.r, w = d.w;
     const double *L = pool + d.lpan;
+    // the first rounds of slot indices: lane t holds the sources of row t (one round trip for up to SR rounds)
+    constexpr int SR = 4;
+    const int rounds = d.rl_count, stride = (r + 15) & ~15;
+    const int *sl = slots + d.rl_begin;
+    int sidx[SR];
+#pragma unroll
+    for (int j = 0; j < SR; ++j) sidx[j] = (j < rounds && lane < r) ? sl[j * stride + lane] : -1;
     PanelRegs<RMAX> P;                                         // P(i, k) = L(i, k), zero outside r x w
     {
         const int i = P.row_of(lane);
@@ -1336,49 +1347,39 @@ k_fwd_rhs(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ r
     double rd = 1.0;
     if (KIND == CS3_CHOLESKY) rd = L[(lane < w ? lane : 0) * (long long) (r + 1)];
     // own rows of X, zeros below them
+    double v[RMAX + (RMAX == 16 ? 1 : 0)];                     // (17, not 16: hipcc turns a 16-double array into a vector
+                                                               //  value and spills 3 k registers around its updates)
 #pragma unroll
     for (int t = 0; t < RMAX; ++t) {
-        double x0 = 0.0;
-        if (t < w) x0 = Xin[(long long) bcast_lane_i(qrow, t) * nrhs + lo];
-        vl[t * 64 + lane] = x0;
+        v[t] = 0.0;
+        if (t < w) v[t] = Xin[(long long) bcast_lane_i(qrow, t) * nrhs + lo];
     }
-    // what the children add, sorted by target: sum a run in a register, add it once
-    {
-        const int np = d.rl_count;                             // multiple of 16
-        const int *pr = rl + 2 * d.rl_begin;
-        int cur = -1;
-        double acc = 0.0;
-        for (int base = 0; base < np; base += 64) {
-            const int have = min(64, np - base);
-            const int e = base + (lane < have ? lane : 0);
-            const int ptg = pr[2 * e], psr = pr[2 * e + 1];    // pair `lane` of this block of 64
-            double nxt[16];
+    // what the children add: round by round, 16 rows at a time -- 16 independent loads, then 16 additions into
+    // statically indexed registers; a (round, 16 rows) block without any source is skipped
+    for (int j0 = 0; j0 < rounds; j0 += SR) {
+        if (j0 > 0) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) nxt[u] = cv[(long long) bcast_lane_i(psr, u) * nrhs + lo];
-            for (int c = 0; c < have; c += 16) {
-                double val[16];
+            for (int j = 0; j < SR; ++j) sidx[j] = (j0 + j < rounds && lane < r) ? sl[(j0 + j) * stride + lane] : -1;
+        }
 #pragma unroll
-                for (int u = 0; u < 16; ++u) val[u] = nxt[u];
-                if (c + 16 < have) {
+        for (int j = 0; j < SR; ++j) {
+            if (j0 + j >= rounds) break;
+            const unsigned long long has = __builtin_amdgcn_ballot_w64(sidx[j] >= 0);
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) nxt[u] = cv[(long long) bcast_lane_i(psr, c + 16 + u) * nrhs + lo];
-                }
+            for (int t0 = 0; t0 < RMAX; t0 += 16) {
+                if (t0 < r && ((has >> t0) & 0xffffull)) {
+                    double val[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int tg = bcast_lane_i(ptg, c + u);
-                    if (tg != cur) {                           // wave-uniform
-                        if (cur >= 0) vl[cur * 64 + lane] += acc;
-                        cur = tg; acc = 0.0;
+                    for (int u = 0; u < 16; ++u) {
+                        const int sx = bcast_lane_i(sidx[j], t0 + u);
+                        val[u] = load_if(cv, (long long) sx * nrhs + lo, sx >= 0);
                     }
-                    acc += (tg >= 0) ? val[u] : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[t0 + u] += val[u];
                 }
             }
         }
-        if (cur >= 0) vl[cur * 64 + lane] += acc;
     }
-    double v[RMAX];
-#pragma unroll
-    for (int t = 0; t < RMAX; ++t) v[t] = vl[t * 64 + lane];
     if (KIND == CS3_CHOLESKY) rd = 1.0 / rd;                   // 1 / L(k, k), pivot k in lane k
 #pragma unroll
     for (int k = 0; k < RMAX; ++k) {
@@ -1408,7 +1409,7 @@ k_fwd_rhs(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ r
 // are final), one descending recurrence  x[t] final -> x[i] -= M(i, t) x[t]  for the pivot rows i < t,
 // with M = [U11 U12] (Cholesky: [L11' L21']) and zero rows below w.
 template <int KIND, int RMAX>
-__global__ void __launch_bounds__(64, (RMAX <= 32) ? 2 : 1)
+__global__ void __launch_bounds__(64, (RMAX <= 16) ? 4 : (RMAX <= 32) ? 2 : 1)
 k_bwd_rhs(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ st_idx,
           const double *__restrict__ pool_all, double *X_all,
           int nrhs, long long pool_stride, long long x_stride, XMap xm)
@@ -1439,7 +1440,7 @@ k_bwd_rhs(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ s
         }
     }
     double rd = L[(lane < w ? lane : 0) * (long long) (r + 1)];
-    double x[RMAX];
+    double x[RMAX + (RMAX == 16 ? 1 : 0)];                     // (17: see k_fwd_rhs)
 #pragma unroll
     for (int t = 0; t < RMAX; ++t) {
         x[t] = 0.0;
@@ -1500,7 +1501,7 @@ k_fwd_blk(const SolveDesc *__restrict__ sd, int first,
     double *y = v + r + 1;
     for (int i = tid; i < r; i += 256) v[i] = 0.0;
     __syncthreads();
-    gather_front(d.fasm_begin, d.fasm_count >> 6, (tid >> 6) * GATHER_UNROLL, 4 * GATHER_UNROLL, fsrc, ftgt, flong,
+    gather_front(d.fasm_begin, d.fasm_count >> 6, tid >> 6, 4, fsrc, ftgt, flong,
                  [&](int q) -> const double * {
                      return (q >= 0) ? cv + (long long) q * nrhs + rhs : X + (long long) (~q) * nrhs + rhs;
                  },
@@ -1637,7 +1638,7 @@ k_fwd_big_gather(const SolveDesc *__restrict__ sd, int first,
     double *v = bigv_all + ((long long) b * nrhs + rhs) * bv_size + d.bv;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     // rows without any source (none in practice: every row has X or a child) keep what the init wrote
-    gather_front(d.fasm_begin, d.fasm_count >> 6, wave * GATHER_UNROLL, gridDim.x * 4 * GATHER_UNROLL, fsrc, ftgt, flong,
+    gather_front(d.fasm_begin, d.fasm_count >> 6, wave, gridDim.x * 4, fsrc, ftgt, flong,
                  [&](int q) -> const double * {
                      return (q >= 0) ? cv + (long long) q * nrhs + rhs : X + (long long) (~q) * nrhs + rhs;
                  },
@@ -2410,27 +2411,62 @@ k_inv_diag(const SolveDesc *__restrict__ sd, const int *__restrict__ tasks, int 
     }
 }
 
-// Front vector of the GEMM fronts from the gather lists (as k_fwd_big_gather), written row-major [row][rhs].
+// Front vector of the GEMM fronts, row-major [row][rhs]: one wave per row and tile of 64 right-hand sides (a row of the
+// tile is one coalesced 512-byte access).  Row t = its own row of X (pivot rows, through the row map when the
+// permutation is fused) + the sources of its slot rounds in order (SolveDesc::rl_begin); every row of the vector is
+// written, so the buffer needs no zeroing.  Workgroup = 16 rows, 4 per wave.
 __global__ void __launch_bounds__(256)
-k_gemm_gather(const SolveDesc *__restrict__ sd, int first,
-              const int *__restrict__ fsrc, const int *__restrict__ ftgt, const int *__restrict__ flong,
+k_gemm_gather(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ slots,
               const double *__restrict__ cv_all, const double *__restrict__ X_all, double *__restrict__ gv_all,
-              int nrhs, long long cv_stride, long long x_stride, long long gv_stride, XMap xm)
+              int nrhs, long long cv_stride, long long x_stride, long long gv_stride, XMap xm, int batch)
 {
-    const SolveDesc d = sd[first + blockIdx.z];
-    const int b = blockIdx.y / nrhs, rhs = blockIdx.y % nrhs;
+    const SolveDesc d = sd[first + blockIdx.z / batch];
+    const int b = blockIdx.z % batch;
+    const int r = d.r, w = d.w, rounds = d.rl_count, stride = (r + 15) & ~15;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = blockIdx.y * 64 + lane;
+    const bool live = col < nrhs;
+    const long long lo = live ? col : 0;
     const double *cv = cv_all + (long long) b * cv_stride;
     const double *X = (xm.src ? xm.src : X_all) + (long long) b * x_stride;
-    const int *qm = xm.src ? xm.q : nullptr;
-    double *v = gv_all + (long long) b * gv_stride + d.gv * (long long) nrhs + rhs;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    gather_front(d.fasm_begin, d.fasm_count >> 6, wave * GATHER_UNROLL, gridDim.x * 4 * GATHER_UNROLL, fsrc, ftgt, flong,
-                 [&](int q) -> const double * {
-                     if (q >= 0) return cv + (long long) q * nrhs + rhs;
-                     const int row = qm ? qm[~q] : ~q;
-                     return X + (long long) row * nrhs + rhs;
-                 },
-                 [&](int t, double val) { v[(long long) t * nrhs] = val; });
+    double *V = gv_all + (long long) b * gv_stride + d.gv * (long long) nrhs;
+    const int *sl = slots + d.rl_begin;
+    const int t0 = blockIdx.x * 16 + wv * 4;
+    int rowx[4], sv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                               // both index loads of my four rows in one round trip
+        const int t = t0 + u;
+        rowx[u] = (t < w) ? (xm.src ? xm.q[d.c0 + t] : d.c0 + t) : -1;
+        sv[u] = (t < r && lane < rounds) ? sl[lane * stride + t] : -1;          // lane j: source of round j
+    }
+    double acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = load_if(X, (long long) rowx[u] * nrhs + lo, rowx[u] >= 0);
+    for (int j0 = 0; j0 < rounds; j0 += 64) {
+        if (j0 > 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sv[u] = (t0 + u < r && j0 + lane < rounds) ? sl[(j0 + lane) * stride + t0 + u] : -1;
+        }
+        const int nj = min(64, rounds - j0);
+        for (int jb = 0; jb < nj; jb += 4) {
+            double val[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int sx = bcast_lane_i(sv[u], (jb + j) & 63);
+                    val[u][j] = load_if(cv, (long long) sx * nrhs + lo, sx >= 0);
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[u] += val[u][j];
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (t0 + u < r) V[(long long) (t0 + u) * nrhs + col] = acc[u];
 }
 
 // 64 x 64 x 64 product on the matrix cores, operands in LDS: acc(i, n) += sgn * A(i, k) B(k, n), with
@@ -2566,21 +2602,36 @@ k_gemm_bwd_init(const SolveDesc *__restrict__ sd, int first, const int *__restri
             acc[nt][v] = load_if(X, (long long) (d.c0 + i) * nrhs + n0 + n, i < w && n < nlive);
         }
     for (int jb = 0; jb < nb; jb += GC) {
-        __syncthreads();
-        for (int e = tid; e < GC * GC; e += 256) {
+        // all 32 global loads of a thread go out together (the ancestors' row numbers one round trip ahead of their rows)
+        int arow[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int k = (tid >> 6) + 4 * q;
+            arow[q] = st[(jb + k < nb) ? w + jb + k : 0];
+        }
+        double ua[16], xb[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + 256 * q;
             {   // As[k][i] = U(i0 + i, w + jb + k)
                 const int k = (KIND == CS3_LU) ? e >> 6 : e & 63, i = (KIND == CS3_LU) ? e & 63 : e >> 6;
                 const bool in = i0 + i < w && jb + k < nb;
                 const long long off = (KIND == CS3_LU) ? d.upan + (long long) (i0 + i) * d.u_sk + (long long) (jb + k) * d.u_sj
                                                        : d.lpan + (long long) (w + jb + k) + (long long) (i0 + i) * r;
-                As[k * GLD + i] = load_if(pool, off, in);
+                ua[q] = load_if(pool, off, in);
             }
             {   // Bs[k][n] = X(row of ancestor w + jb + k, n0 + n)
                 const int k = e >> 6, n = e & 63;
-                const bool in = jb + k < nb && n < nlive;
-                const int row = st[in ? w + jb + k : 0];
-                Bs[k * GLD + n] = load_if(X, (long long) row * nrhs + n0 + n, in);
+                xb[q] = load_if(X, (long long) arow[q] * nrhs + n0 + n, jb + k < nb && n < nlive);
             }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + 256 * q;
+            const int k = (KIND == CS3_LU) ? e >> 6 : e & 63, i = (KIND == CS3_LU) ? e & 63 : e >> 6;
+            As[k * GLD + i] = ua[q];
+            Bs[(e >> 6) * GLD + (e & 63)] = xb[q];
         }
         __syncthreads();
         gemm64<true>(As, Bs, acc, wv, mi, mq);
@@ -3269,8 +3320,8 @@ static hipError_t launch_gemm_group(const DeviceFactor &D, const LaunchGroup &g,
     const int nchunk = (g.max_w + GC - 1) / GC;
     const unsigned slices = (unsigned) std::max(1, (g.max_r + GC - 1) / GC);
     if (forward) {
-        hipLaunchKernelGGL(k_gemm_gather, dim3(4, batch * (unsigned) nrhs, g.count), dim3(256), 0, st, D.sdesc, g.first, D.fasm_src,
-                           D.fasm_tgt, D.flong_src, D.cv, X, D.gv, nrhs, cvs, xs, gvs, D.xm);
+        hipLaunchKernelGGL(k_gemm_gather, dim3((unsigned) ((g.max_r + 15) / 16), tiles, g.count * batch), dim3(256), 0, st, D.sdesc,
+                           g.first, D.sl_src, D.cv, X, D.gv, nrhs, cvs, xs, gvs, D.xm, (int) batch);
         CS3_LAUNCH_CHECK();
         for (int c = 0; c < nchunk; ++c) {
             hipLaunchKernelGGL((k_gemm_fwd<KIND>), dim3(slices, tiles, g.count * batch), dim3(256), GEMM_LDS, st, D.sdesc, g.first, c,
@@ -3297,7 +3348,7 @@ static void launch_rhs_sweep(const DeviceFactor &D, int first, int count, double
     const long long xs = D.n * (long long) nrhs, cvs = D.cv_size * (long long) nrhs;
     dim3 grid((unsigned) count, (unsigned) D.batch, (unsigned) ((nrhs + 63) / 64));
     if (forward)
-        hipLaunchKernelGGL((k_fwd_rhs<KIND, RMAX>), grid, dim3(64), 0, st, D.sdesc, first, D.rl_pairs, D.pool_pm, D.cv, X,
+        hipLaunchKernelGGL((k_fwd_rhs<KIND, RMAX>), grid, dim3(64), 0, st, D.sdesc, first, D.sl_src, D.pool_pm, D.cv, X,
                            nrhs, D.pm_stride, cvs, xs, D.xm);
     else
         hipLaunchKernelGGL((k_bwd_rhs<KIND, RMAX>), grid, dim3(64), 0, st, D.sdesc, first, D.st_idx, D.pool_pm, X,
@@ -3322,14 +3373,13 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
             hipLaunchKernelGGL((k_bwd_il<KIND, IL_RMAX>), grid, dim3(64), 0, st, D.sdesc, g.first, D.st_idx,
                                IlView{D.pool_il, D.il_len}, X, nrhs, xs, (int) D.batch);
     } else if (g.cls == SK_SMALL && nrhs >= RHS_LANES_MIN) {
-        // the fronts of order <= 16 come first in the group: half the registers and LDS per wave, twice the waves per CU
+        // the fronts of order <= 16 come first in the group: half the registers per wave, twice the waves per CU
         // (these sweeps are bound by memory latency times occupancy); the two launches are independent
         static const bool split16 = !(getenv("CS3_NO_SPLIT16") && getenv("CS3_NO_SPLIT16")[0] == '1');
-        // (forward only: the backward kernel keeps no vector in LDS and its 24-row instance already runs 5 waves per SIMD)
-        const int n16 = (split16 && forward && nrhs >= 256 && g.max_r > 16) ? g.n16 : 0;     // (an extra launch per level: pays with many tiles)
+        const int n16 = (split16 && nrhs >= 256 && g.max_r > 16) ? g.n16 : 0;     // (an extra launch per level: pays with many tiles)
         if (n16 > 0) launch_rhs_sweep<KIND, 16>(D, g.first, n16, X, nrhs, forward, st);
         const int f2 = g.first + n16, c2 = g.count - n16;
-        if (g.max_r <= 16 && forward) launch_rhs_sweep<KIND, 16>(D, f2, c2, X, nrhs, forward, st);
+        if (g.max_r <= 16) launch_rhs_sweep<KIND, 16>(D, f2, c2, X, nrhs, forward, st);
         else if (g.max_r <= 24) launch_rhs_sweep<KIND, 24>(D, f2, c2, X, nrhs, forward, st);
         else if (g.max_r <= 32) launch_rhs_sweep<KIND, 32>(D, f2, c2, X, nrhs, forward, st);
         else launch_rhs_sweep<KIND, 64>(D, f2, c2, X, nrhs, forward, st);
@@ -3396,17 +3446,16 @@ hipError_t launch_solve_levels(const DeviceFactor &D, const std::vector<LaunchGr
 {
     const std::vector<LaunchGroup> groups = sweep_groups(all_groups, nrhs);
     fj.rewind();
-    // the sweeps' per-level launches are short: fork/join costs more than it hides (measured), so they stay in line
-    static const bool solve_parallel = getenv("CS3_SOLVE_FORK") && getenv("CS3_SOLVE_FORK")[0] == '1';
+    // one right-hand side: the per-level launches are short, fork/join costs more than it hides (measured), so they stay
+    // in line.  Many right-hand sides: the lane = right-hand-side group and the GEMM group of a level take 10-40 us each
+    // and are independent -- side by side they save 60 us of 1.73 ms at 1024 right-hand sides, 24 us of 0.83 at 128.
+    static const char *sf = getenv("CS3_SOLVE_FORK");
+    const bool solve_parallel = sf ? sf[0] == '1' : nrhs >= RHS_LANES_MIN;
     auto launch = [&](const LaunchGroup &g, hipStream_t s) {
         return (D.kind == CS3_LU) ? launch_solve_group<CS3_LU>(D, g, X, nrhs, forward, s)
                                   : launch_solve_group<CS3_CHOLESKY>(D, g, X, nrhs, forward, s);
     };
     if (forward) {
-        if (nrhs >= RHS_LANES_MIN && D.gv_size > 0) {         // rows of a front vector that no source touches start at zero
-            hipError_t me = hipMemsetAsync(D.gv, 0, (size_t) (D.batch * D.gv_size * nrhs) * sizeof(double), st);
-            if (me != hipSuccess) return me;
-        }
         for (size_t g0 = 0; g0 < groups.size(); ) {
             size_t g1 = g0;
             while (g1 < groups.size() && groups[g1].level == groups[g0].level) ++g1;
@@ -3448,9 +3497,6 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
     const std::vector<LaunchGroup> sgroups = sweep_groups(all_sgroups, nrhs);
     fj.rewind();
     hipError_t e;
-    if (nrhs >= RHS_LANES_MIN && D.gv_size > 0) {             // front vectors of the GEMM sweeps start at zero
-        if ((e = hipMemsetAsync(D.gv, 0, (size_t) (D.batch * D.gv_size * nrhs) * sizeof(double), st)) != hipSuccess) return e;
-    }
     const int nlevels = fgroups.empty() ? 0 : fgroups.back().level + 1;
     std::vector<long long> tail(nlevels + 1, 0), head(nlevels + 1, 0);   // factor cost of levels >= l; sweep cost of levels < l
     for (const LaunchGroup &g : fgroups) tail[g.level] += factor_group_cost(g);

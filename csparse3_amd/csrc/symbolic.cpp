@@ -624,9 +624,13 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
             S.fasm_ptr[s + 1] = (i64) S.fasm_tgt.size();
         }
     }
+    // lane = right-hand-side sweeps serve fronts up to this order; beyond it the GEMM sweeps (inverted diagonal blocks,
+    // f64 MFMA) take over.  32 since round 2: the 64-row instance of the lane = right-hand-side kernels holds 128 register
+    // pairs per lane (one wave per SIMD) and measured 45 us per level on a handful of fronts, the GEMM pair 19.
+    static const i64 small_rmax = std::getenv("CS3_RHS_LANES_RMAX") ? std::atoll(std::getenv("CS3_RHS_LANES_RMAX")) : 32;
     auto solve_kind = [&](i32 s) {
         if (S.sn_class[s] == FC_IL) return (int) SK_IL;
-        if (order_r(s) <= 64) return (int) SK_SMALL;
+        if (order_r(s) <= small_rmax) return (int) SK_SMALL;
         if (order_r(s) <= 128 && width(s) <= 64) return (int) SK_WAVE;
         // wide big fronts: one launch per chunk with many workgroups for a lone matrix; a batch fills the chip with one
         // workgroup per (front, matrix), so there the single-launch block kernel is the shorter path
@@ -635,27 +639,47 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     S.bv_off.assign(ns, 0); S.bv_size = 0;
     for (i32 s = 0; s < ns; ++s)
         if (solve_kind(s) == SK_BIG) { S.bv_off[s] = S.bv_size; S.bv_size += order_r(s); }
-    // many right-hand sides, fronts of order <= 64 (lane = right-hand side): what the children add to
-    // the front vector as plain (target, source) pairs sorted by target, padded to a multiple of 16
-    // with target -1
+    // lane = matrix sweeps (SK_IL): what the children add to the front vector as plain (target, source) pairs sorted by
+    // target, padded to a multiple of 16 with target -1.
+    // every other front (16 or more right-hand sides: lane = right-hand side, GEMM sweeps): the same additions as SLOT ROUNDS -- round j
+    // holds, for every row t of the front, the j-th source that adds to it (children in order) or -1; a round is
+    // stride = 16 ceil(r / 16) entries, so lane t reads its slot of a round with one coalesced load and the sweep
+    // issues the additions of 16 rows at a time with statically indexed registers (no LDS, no data-dependent targets).
     S.rl_ptr.assign(ns + 1, 0);
     S.rl_pairs.clear();
+    S.sl_ptr.assign(ns + 1, 0);
+    S.sl_rounds.assign(ns, 0);
+    S.sl_src.clear();
     {
         std::vector<Item> items;
+        std::vector<i32> fill;
         for (i32 s = 0; s < ns; ++s) {
-            if (solve_kind(s) == SK_SMALL || solve_kind(s) == SK_IL) {
-                items.clear();
-                for (i32 cp = S.child_ptr[s]; cp < S.child_ptr[s + 1]; ++cp) {
-                    const i32 c = S.child_idx[cp];
-                    const i64 nbc = order_r(c) - width(c);
-                    const i32 *rel = S.rel_idx.data() + S.rel_ptr[c];
-                    for (i64 ii = 0; ii < nbc; ++ii) items.push_back(Item{rel[ii], (i32) (S.cv_off[c] + ii)});
-                }
-                std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.tgt < b.tgt; });
+            const int sk = solve_kind(s);
+            items.clear();
+            for (i32 cp = S.child_ptr[s]; cp < S.child_ptr[s + 1]; ++cp) {
+                const i32 c = S.child_idx[cp];
+                const i64 nbc = order_r(c) - width(c);
+                const i32 *rel = S.rel_idx.data() + S.rel_ptr[c];
+                for (i64 ii = 0; ii < nbc; ++ii) items.push_back(Item{rel[ii], (i32) (S.cv_off[c] + ii)});
+            }
+            std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.tgt < b.tgt; });
+            if (sk == SK_IL) {
                 for (const Item &it : items) { S.rl_pairs.push_back(it.tgt); S.rl_pairs.push_back(it.src); }
                 while ((S.rl_pairs.size() / 2) % 16) { S.rl_pairs.push_back(-1); S.rl_pairs.push_back(0); }
             }
+            if (sk != SK_IL) {
+                const i64 r = order_r(s), stride = (r + 15) / 16 * 16;
+                fill.assign((size_t) r, 0);
+                i32 rounds = 0;
+                for (const Item &it : items) rounds = std::max(rounds, ++fill[(size_t) it.tgt]);
+                const size_t base = S.sl_src.size();
+                S.sl_src.resize(base + (size_t) (rounds * stride), -1);
+                std::fill(fill.begin(), fill.end(), 0);
+                for (const Item &it : items) S.sl_src[base + (size_t) (fill[(size_t) it.tgt]++ * stride + it.tgt)] = it.src;
+                S.sl_rounds[s] = rounds;
+            }
             S.rl_ptr[s + 1] = (i64) (S.rl_pairs.size() / 2);
+            S.sl_ptr[s + 1] = (i64) S.sl_src.size();
         }
     }
     S.ssched.resize(ns);

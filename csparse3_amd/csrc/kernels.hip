@@ -608,15 +608,28 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
     const int ld = r | 1;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, li = lane & 31;
     const bool stacked = lane >= 32;
+    // The image.  LU: column-major with the odd leading dimension ld.  Cholesky: only the lower triangle exists,
+    // PACKED by columns (entry (i, j), i >= j, at i + j (2 r - 1 - j) / 2): half the LDS, so twice the workgroups per CU
+    // -- the phases of one front are serial (gather, one-wave eliminations, barriers) and a batch hides them only with
+    // other fronts on the same CU.  F[img] (one past the image) stays zero for the masked loads.
+    const int img = (KIND == CS3_LU) ? r * ld : (r * (r + 1)) >> 1;
+    auto at = [&](int i, int j) -> int { return (KIND == CS3_LU) ? i + j * ld : i + ((j * (2 * r - 1 - j)) >> 1); };
 
     // ---- assemble: F = sum of sources (A entries, children's contribution blocks)
     CS3_STAMP(0);
-    for (int i = tid; i < r * ld + 1; i += 512) F[i] = 0.0;
+    for (int i = tid; i < img + 1; i += 512) F[i] = 0.0;
     __syncthreads();
     CS3_STAMP(1);
+    const float inv_ld = 1.0f / (float) ld;
     gather_front<GATHER_UNROLL_WG>(d.asm_begin, d.asm_count >> 6, wv, 8, asm_src, asm_tgt, long_src,
                  [&](int q) -> const double * { return (q >= 0) ? ((q < il.len) ? pil + (long long) q * 64 : pool + q) : ax + ~q; },
-                 [&](int t, double v) { F[t] = v; });
+                 [&](int t, double v) {
+                     if (KIND == CS3_LU) { F[t] = v; return; }
+                     int j = (int) ((float) t * inv_ld);            // the list's targets are i + j ld: unpack (t < 2^15)
+                     j += ((j + 1) * ld <= t) ? 1 : 0;
+                     j -= (j * ld > t) ? 1 : 0;
+                     F[at(t - j * ld, j)] = v;
+                 });
     __syncthreads();
     CS3_STAMP(2);
 
@@ -632,15 +645,16 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
         const bool active = !(KIND == CS3_CHOLESKY && row_wave) && (owner || s0 < r);
         double e[NBK];
         if (active) {
-            // entry j of my row: one LDS read at base + j * stride.  Block lanes: D (D' for a row wave), identity past
-            // bw; stacked lanes: my row of the block column (my column of the block row for a row wave)
+            // entry j of my row: one LDS read.  Block lanes: D (D' for a row wave), identity past bw; stacked lanes: my
+            // row of the block column (my column of the block row for a row wave).  Cholesky reads the lower triangle.
             const int line = stacked ? si : kb + li;
-            const int base = row_wave ? kb + line * ld : line + kb * ld, stride = row_wave ? 1 : ld;
             const bool mine = stacked ? si < r : li < bw;
 #pragma unroll
             for (int j = 0; j < NBK; ++j) {
-                const double v = F[(mine && j < bw) ? base + j * stride : 0];
-                e[j] = (mine && j < bw) ? v : ((!stacked && li == j) ? 1.0 : 0.0);
+                const bool in = mine && j < bw && (KIND == CS3_LU || stacked || li >= j);
+                const int off = (KIND == CS3_LU) ? (row_wave ? kb + j + line * ld : line + (kb + j) * ld) : at(line, kb + j);
+                const double v = F[in ? off : img];
+                e[j] = in ? v : ((!stacked && li == j) ? 1.0 : 0.0);
             }
         }
         __syncthreads();                                    // everybody has read D before wave 0 writes its factors back
@@ -661,14 +675,14 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
                                 rej = (li == j) & !(v > 0.0);
                             }
                             if (rej && !bad) { bad = true; bad_col = kb + j; }
-                            F[(kb + li) + (kb + j) * ld] = v;
+                            if (KIND == CS3_LU || li >= j) F[at(kb + li, kb + j)] = v;
                         }
                     } else if (si < r) {
                         if (!row_wave) {
                             if (KIND == CS3_LU && !(av <= inv_tol) && !bad) { bad = true; bad_col = kb + j; }
-                            F[si + (kb + j) * ld] = v;
+                            F[at(si, kb + j)] = v;
                         } else {
-                            F[(kb + j) + si * ld] = v;
+                            F[at(kb + j, si)] = v;
                         }
                     }
                 }
@@ -686,7 +700,8 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int c = ke + 16 * tj + mq + 4 * v;
-                    acc[v] = (i < r && c < r) ? F[i + c * ld] : 0.0;
+                    const bool in = i < r && c < r && (KIND == CS3_LU || i >= c);
+                    acc[v] = F[in ? at(i, c) : img];
                 }
                 const int ca = ke + 16 * tj + mi;               // A operand: U(kb + k, column ca) (Cholesky: L(ca, kb + k))
 #pragma unroll
@@ -694,15 +709,15 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
                     if (k0 < bw) {
                         const int k = kb + k0 + mq;
                         const bool kin = k0 + mq < bw;
-                        const double au = (kin && ca < r) ? ((KIND == CS3_LU) ? F[k + ca * ld] : F[ca + k * ld]) : 0.0;
-                        const double bl = (kin && i < r) ? -F[i + k * ld] : 0.0;
+                        const double au = F[(kin && ca < r) ? ((KIND == CS3_LU) ? k + ca * ld : at(ca, k)) : img];
+                        const double bl = -F[(kin && i < r) ? at(i, k) : img];
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(au, bl, acc, 0, 0, 0);
                     }
                 }
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int c = ke + 16 * tj + mq + 4 * v;
-                    if (i < r && c < r) F[i + c * ld] = acc[v];
+                    if (i < r && c < r && (KIND == CS3_LU || i >= c)) F[at(i, c)] = acc[v];
                 }
             }
         }
@@ -718,7 +733,7 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
     const bool has_parent = d.parent >= 0;
     for (int e = tid; e < r * w; e += 512) {                    // L panel, column-major r x w
         const int i = e % r, j = e / r;
-        if (KIND == CS3_LU || i >= j) L[e] = F[i + j * ld];
+        if (KIND == CS3_LU || i >= j) L[e] = F[at(i, j)];
     }
     if (KIND == CS3_LU)
         for (int e = tid; e < w * nb; e += 512) {               // U panel: pivot rows contiguous (u_sk = 1, u_sj = w)
@@ -728,7 +743,7 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
     if (has_parent)
         for (int e = tid; e < nb * nb; e += 512) {
             const int i = e % nb, j = e / nb;
-            if (KIND == CS3_LU || i >= j) cb[e] = F[(w + i) + (w + j) * ld];
+            if (KIND == CS3_LU || i >= j) cb[e] = F[at(w + i, w + j)];
         }
     CS3_STAMP(5);
 #undef CS3_STAMP
@@ -748,8 +763,8 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
 // Two block barriers per 32 pivots, no grid-wide dependency.  Used when the batch alone fills the chip and the
 // panels fit the LDS (launch_front_group decides); results equal k_big_step's to rounding, not bit for bit
 // (the MFMA sums 32 products per step either way, but the diagonal block is updated tile-wise here).
-template <int KIND>
-__global__ void __launch_bounds__(512)
+template <int KIND, int NB>
+__global__ void __launch_bounds__(512, (NB <= 16) ? 4 : 2)
 k_front_wg(const FrontDesc *__restrict__ fdesc, int first,
            const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
            const double *__restrict__ ax_all, double *__restrict__ pool_all,
@@ -772,8 +787,8 @@ k_front_wg(const FrontDesc *__restrict__ fdesc, int first,
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, li = lane & 31;
     const bool stacked = lane >= 32;
     double *Dl = sm;                           // Dl[j * 33 + i] = D(i, j)
-    double *Lp = sm + BIG_NB * 33;             // Lp[k * pld + i] = L(ke + i, kb + k)
-    double *Up = Lp + BIG_NB * pld;            // Up[k * pld + j] = U(kb + k, ke + j)   (LU only)
+    double *Lp = sm + NB * 33;             // Lp[k * pld + i] = L(ke + i, kb + k)
+    double *Up = Lp + NB * pld;            // Up[k * pld + j] = U(kb + k, ke + j)   (LU only)
 
     // ---- assemble: zero the buffer, then F = sum of sources (A entries, children's contribution blocks)
     for (long long e = tid; e < (long long) r * r; e += 512) F[e] = 0.0;
@@ -787,11 +802,11 @@ k_front_wg(const FrontDesc *__restrict__ fdesc, int first,
 
     bool bad = false;
     int bad_col = 0;
-    for (int kb = 0; kb < w; kb += BIG_NB) {
-        const int bw = min(BIG_NB, w - kb), ke = kb + bw, nrem = r - ke;
+    for (int kb = 0; kb < w; kb += NB) {
+        const int bw = min(NB, w - kb), ke = kb + bw, nrem = r - ke;
         if (prof) t_mark = (long long) __builtin_amdgcn_s_memtime();
-        for (int e = tid; e < BIG_NB * BIG_NB; e += 512) {
-            const int i = e & 31, j = e >> 5;
+        for (int e = tid; e < NB * NB; e += 512) {
+            const int i = e % NB, j = e / NB;
             Dl[j * 33 + i] = load_if(F, (kb + i) + (long long) (kb + j) * ld, i < bw && j < bw);
         }
         __syncthreads();
@@ -803,10 +818,10 @@ k_front_wg(const FrontDesc *__restrict__ fdesc, int first,
             const bool row_wave = t >= ng;
             const int grp = row_wave ? t - ng : t, s0 = ke + 32 * grp, si = s0 + li;
             const bool owner = t == 0;
-            double e[BIG_NB];
+            double e[NB];
             if (!stacked) {
 #pragma unroll
-                for (int j = 0; j < BIG_NB; ++j) {
+                for (int j = 0; j < NB; ++j) {
                     const double v = row_wave ? Dl[li * 33 + j] : Dl[j * 33 + li];
                     e[j] = (li < bw && j < bw) ? v : ((li == j) ? 1.0 : 0.0);
                 }
@@ -815,11 +830,11 @@ k_front_wg(const FrontDesc *__restrict__ fdesc, int first,
                 const long long base = row_wave ? (long long) kb + (long long) si * ld : (long long) si + (long long) kb * ld;
                 const long long stride = row_wave ? 1 : ld;
 #pragma unroll
-                for (int j = 0; j < BIG_NB; ++j) e[j] = load_if(F, base + j * stride, mine && j < bw);
+                for (int j = 0; j < NB; ++j) e[j] = load_if(F, base + j * stride, mine && j < bw);
             }
-            eliminate_block<KIND, BIG_NB>(e, row_wave);
+            eliminate_block<KIND, NB>(e, row_wave);
 #pragma unroll
-            for (int j = 0; j < BIG_NB; ++j) {
+            for (int j = 0; j < NB; ++j) {
                 if (j < bw) {
                     const double v = e[j], av = fabs(v);
                     if (!stacked) {
@@ -865,7 +880,7 @@ k_front_wg(const FrontDesc *__restrict__ fdesc, int first,
                     acc[v] = load_if(F, i + (long long) c * ld, i < r && c < r);
                 }
 #pragma unroll
-                for (int k0 = 0; k0 < BIG_NB; k0 += 4) {
+                for (int k0 = 0; k0 < NB; k0 += 4) {
                     if (k0 < bw) {
                         const int k = k0 + mq;
                         const bool kin = k < bw;
@@ -888,7 +903,7 @@ k_front_wg(const FrontDesc *__restrict__ fdesc, int first,
     if (prof) {
         tbuf[(long long) (first + blockIdx.x) * 8 + 2] = t_panel;
         tbuf[(long long) (first + blockIdx.x) * 8 + 3] = t_update;
-        tbuf[(long long) (first + blockIdx.x) * 8 + 4] = (w + BIG_NB - 1) / BIG_NB;
+        tbuf[(long long) (first + blockIdx.x) * 8 + 4] = (w + NB - 1) / NB;
     }
     CS3_WSTAMP(5);
 #undef CS3_WSTAMP
@@ -3017,9 +3032,12 @@ static hipError_t launch_big_block(const DeviceFactor &D, const LaunchGroup &g, 
 
 // One workgroup per (big front, matrix) when the batch fills the chip by itself and the panels fit the LDS.
 static int wg_panel_ld(const LaunchGroup &g) { return (g.max_r + 1) | 1; }
+// pivots per block step: 16 keeps the kernel within 128 registers, i.e. two workgroups per CU (its phases are serial and
+// latency-bound: 512 matrices took 809 us with one workgroup per CU, in two rounds); CS3_WG_NB=32 is the round-2a form
+static int wg_nb() { static const int nb = (getenv("CS3_WG_NB") && atoi(getenv("CS3_WG_NB")) == 32) ? 32 : 16; return nb; }
 static size_t wg_lds_bytes(int kind, const LaunchGroup &g)
 {
-    return ((size_t) BIG_NB * 33 + (size_t) (kind == CS3_LU ? 2 : 1) * BIG_NB * wg_panel_ld(g)) * sizeof(double);
+    return ((size_t) wg_nb() * 33 + (size_t) (kind == CS3_LU ? 2 : 1) * wg_nb() * wg_panel_ld(g)) * sizeof(double);
 }
 bool big_group_in_one_workgroup(int kind, long long batch, const LaunchGroup &g)
 {
@@ -3032,9 +3050,14 @@ static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g
 {
     const unsigned batch = (unsigned) D.batch;
     if (big_group_in_one_workgroup(KIND, D.batch, g)) {
-        hipLaunchKernelGGL((k_front_wg<KIND>), dim3((unsigned) g.count, batch), dim3(512), wg_lds_bytes(KIND, g), st, D.fdesc,
-                           g.first, D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool_pm, D.nnz_a, D.pm_stride,
-                           IlView{D.pool_il, D.il_len}, inv_tol, D.status, wg_panel_ld(g), D.tbuf);
+        if (wg_nb() == 16)
+            hipLaunchKernelGGL((k_front_wg<KIND, 16>), dim3((unsigned) g.count, batch), dim3(512), wg_lds_bytes(KIND, g), st, D.fdesc,
+                               g.first, D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool_pm, D.nnz_a, D.pm_stride,
+                               IlView{D.pool_il, D.il_len}, inv_tol, D.status, wg_panel_ld(g), D.tbuf);
+        else
+            hipLaunchKernelGGL((k_front_wg<KIND, 32>), dim3((unsigned) g.count, batch), dim3(512), wg_lds_bytes(KIND, g), st, D.fdesc,
+                               g.first, D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool_pm, D.nnz_a, D.pm_stride,
+                               IlView{D.pool_il, D.il_len}, inv_tol, D.status, wg_panel_ld(g), D.tbuf);
         CS3_LAUNCH_CHECK();
         return hipSuccess;
     }
@@ -3065,9 +3088,11 @@ static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g
         // pivots per block step: the one-wave elimination of a block costs NBK^2 column updates, the MFMA update that
         // follows is cheap, so narrow blocks win (measured: 32 -> 16 took 4 % off the batched config, neutral on config 3)
         static const int nbk = getenv("CS3_NBK") ? atoi(getenv("CS3_NBK")) : 16;
-        if (nbk <= 8) hipLaunchKernelGGL((k_front_block<KIND, 8>), grid, dim3(512), lds, st, CS3_FRONT_ARGS);
-        else if (nbk <= 16) hipLaunchKernelGGL((k_front_block<KIND, 16>), grid, dim3(512), lds, st, CS3_FRONT_ARGS);
-        else hipLaunchKernelGGL((k_front_block<KIND, 32>), grid, dim3(512), lds, st, CS3_FRONT_ARGS);
+        // the image: r x (r | 1) for LU, the packed lower triangle for Cholesky, one zero entry behind it
+        const size_t blds = ((KIND == CS3_LU) ? ld * (size_t) g.max_r : (size_t) g.max_r * (size_t) (g.max_r + 1) / 2) * sizeof(double) + 16;
+        if (nbk <= 8) hipLaunchKernelGGL((k_front_block<KIND, 8>), grid, dim3(512), blds, st, CS3_FRONT_ARGS);
+        else if (nbk <= 16) hipLaunchKernelGGL((k_front_block<KIND, 16>), grid, dim3(512), blds, st, CS3_FRONT_ARGS);
+        else hipLaunchKernelGGL((k_front_block<KIND, 32>), grid, dim3(512), blds, st, CS3_FRONT_ARGS);
         break;
     }
 #undef CS3_FRONT_ARGS
@@ -3083,7 +3108,8 @@ hipError_t prepare_kernels()
     const void *block_fns[] = {(const void *) k_front_block<CS3_LU, 16>, (const void *) k_front_block<CS3_LU, 32>,
                                (const void *) k_front_block<CS3_CHOLESKY, 16>, (const void *) k_front_block<CS3_CHOLESKY, 32>,
                                (const void *) k_front_block<CS3_LU, 8>, (const void *) k_front_block<CS3_CHOLESKY, 8>,
-                               (const void *) k_front_wg<CS3_LU>, (const void *) k_front_wg<CS3_CHOLESKY>};
+                               (const void *) k_front_wg<CS3_LU, 16>, (const void *) k_front_wg<CS3_CHOLESKY, 16>,
+                               (const void *) k_front_wg<CS3_LU, 32>, (const void *) k_front_wg<CS3_CHOLESKY, 32>};
     for (const void *f : block_fns) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, big);
         if (e != hipSuccess) return e;
@@ -3152,14 +3178,16 @@ static hipError_t run_level(const std::vector<LaunchGroup> &groups, size_t g0, s
     hipError_t e = fj.event(&fork);
     if (e != hipSuccess) return e;
     if ((e = hipEventRecord(fork, st)) != hipSuccess) return e;
-    // the heaviest group (last: big fronts / block kernels sort last) stays on the main stream
-    std::vector<hipEvent_t> joins;
+    // the heaviest group (last: big fronts / block kernels sort last) stays on the main stream and is captured FIRST: the
+    // runtime keeps a node's first captured dependent in the node's own hardware queue (launch_factor_with_forward)
+    static const bool heavy_first = !(getenv("CS3_SWEEP_FIRST") && getenv("CS3_SWEEP_FIRST")[0] == '1');
+    if (heavy_first && (e = launch(groups[g1 - 1], st)) != hipSuccess) return e;
     for (size_t i = 0; i + 1 < ng; ++i) {
         hipStream_t s = fj.side[i % ForkJoin::NSIDE];
         if (i < (size_t) ForkJoin::NSIDE) { if ((e = hipStreamWaitEvent(s, fork, 0)) != hipSuccess) return e; }
         if ((e = launch(groups[g0 + i], s)) != hipSuccess) return e;
     }
-    if ((e = launch(groups[g1 - 1], st)) != hipSuccess) return e;
+    if (!heavy_first && (e = launch(groups[g1 - 1], st)) != hipSuccess) return e;
     for (size_t i = 0; i < std::min(ng - 1, (size_t) ForkJoin::NSIDE); ++i) {
         hipEvent_t j;
         if ((e = fj.event(&j)) != hipSuccess) return e;
@@ -3533,7 +3561,7 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
             rootf = roots = nullptr;
     }
     hipEvent_t swept = nullptr, ready_deferred = nullptr;
-    static const bool defer_sweep = getenv("CS3_DEFER_SWEEP") && getenv("CS3_DEFER_SWEEP")[0] == '1';
+    static const bool sweep_first = getenv("CS3_SWEEP_FIRST") && getenv("CS3_SWEEP_FIRST")[0] == '1';   // the round-1 capture order
     int root_rest = 0;                             // first chunk of the root's sweep that is still to do after the join
     for (size_t f0 = 0; f0 < fgroups.size(); ) {
         const int level = fgroups[f0].level;
@@ -3543,23 +3571,47 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
             const BigSweepPlan pl = big_sweep_plan(D, *roots, nrhs);
             const int nblk = big_group_blocks(*rootf), cwb = pl.cw / BIG_NB;
             if ((e = launch_big_gather(D, *rootf, st)) != hipSuccess) return e;
-            if (ready_deferred) {                  // experiment: the side branch is captured AFTER the root chain has begun
-                if ((e = hipStreamWaitEvent(fj.aux, ready_deferred, 0)) != hipSuccess) return e;
-                if ((e = sweep(0, fork_level, fj.aux)) != hipSuccess) return e;
-            }
-            if ((e = launch_fwd_big_pre(D, *roots, X, nrhs, fj.aux)) != hipSuccess) return e;
             // ONE release (every cross-stream edge costs the block chain about 10 us): the first k chunks go to
             // fj.aux after block launch k * cwb, k the largest count that the remaining launches still cover;
             // the other chunks follow on st after the join.
+            // CAPTURE ORDER MATTERS: the runtime keeps a node's FIRST captured dependent in the node's own hardware
+            // queue and moves the others to another queue, whose first dispatch then waits 40-60 us (measured:
+            // profiles/r02_timeline_fused_step.json, the root's gather started 46 us after the level below it).  So at
+            // every fork the next launch of the block chain is captured BEFORE the side branch that hangs off the same
+            // node: the chain stays in its queue, the late start lands on the sweep, which has slack.
             int k = 0;
             while (k < pl.nchunk && (k + 1) * cwb <= nblk && nblk - (k + 1) * cwb >= k + 1) ++k;
+            if (const char *rk = getenv("CS3_ROOT_K")) k = std::max(0, std::min(k, atoi(rk)));
             static const bool absorb = !(getenv("CS3_NO_ABSORB") && getenv("CS3_NO_ABSORB")[0] == '1');
+            hipEvent_t home = nullptr;
+            bool side_started = false;
+            auto start_side = [&]() -> hipError_t {                        // sweep of the lower levels + the root's gather
+                side_started = true;
+                if (ready_deferred) {
+                    hipError_t se;
+                    if ((se = hipStreamWaitEvent(fj.aux, ready_deferred, 0)) != hipSuccess) return se;
+                    if ((se = sweep(0, fork_level, fj.aux)) != hipSuccess) return se;
+                }
+                return launch_fwd_big_pre(D, *roots, X, nrhs, fj.aux);
+            };
+            auto release = [&]() -> hipError_t {                           // chunks 0 .. k - 1 hang off block launch k * cwb
+                hipError_t se;
+                if ((se = hipStreamWaitEvent(fj.aux, home, 0)) != hipSuccess) return se;
+                for (int c = 0; c < k; ++c) {
+                    se = (D.kind == CS3_LU) ? launch_fwd_big_chunk<CS3_LU>(D, *roots, X, nrhs, c, fj.aux)
+                                            : launch_fwd_big_chunk<CS3_CHOLESKY>(D, *roots, X, nrhs, c, fj.aux);
+                    if (se != hipSuccess) return se;
+                }
+                home = nullptr;
+                return hipSuccess;
+            };
             for (int blk = 0; blk <= nblk; ++blk) {
                 if (absorb && k > 0 && blk == k * cwb) {
                     // the side branch (sweep of the lower levels, the root's gather) finished long ago: the block chain
                     // absorbs it here, so that the chunks released below hang off the chain alone -- a chunk with two
                     // parents in different queues keeps a barrier pending in the side queue for hundreds of
                     // microseconds, and the chain's dispatches slow down while it does
+                    if (!side_started && (e = start_side()) != hipSuccess) return e;
                     hipEvent_t pre;
                     if ((e = fj.event(&pre)) != hipSuccess) return e;
                     if ((e = hipEventRecord(pre, fj.aux)) != hipSuccess) return e;
@@ -3568,18 +3620,14 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
                 e = (D.kind == CS3_LU) ? launch_big_block<CS3_LU>(D, *rootf, blk, inv_tol, st)
                                        : launch_big_block<CS3_CHOLESKY>(D, *rootf, blk, inv_tol, st);
                 if (e != hipSuccess) return e;
+                if (!side_started && (e = start_side()) != hipSuccess) return e;      // after the chain's first block is captured
+                if (home && (e = release()) != hipSuccess) return e;                  // after the block that follows the release point
                 if (k > 0 && blk == k * cwb) {                         // blocks 0 .. blk - 1 are home
-                    hipEvent_t home;
                     if ((e = fj.event(&home)) != hipSuccess) return e;
                     if ((e = hipEventRecord(home, st)) != hipSuccess) return e;
-                    if ((e = hipStreamWaitEvent(fj.aux, home, 0)) != hipSuccess) return e;
-                    for (int c = 0; c < k; ++c) {
-                        e = (D.kind == CS3_LU) ? launch_fwd_big_chunk<CS3_LU>(D, *roots, X, nrhs, c, fj.aux)
-                                               : launch_fwd_big_chunk<CS3_CHOLESKY>(D, *roots, X, nrhs, c, fj.aux);
-                        if (e != hipSuccess) return e;
-                    }
                 }
             }
+            if (home && (e = release()) != hipSuccess) return e;
             root_rest = k;
             if ((e = fj.event(&swept)) != hipSuccess) return e;           // replaces the join recorded at the fork
             if ((e = hipEventRecord(swept, fj.aux)) != hipSuccess) return e;
@@ -3591,11 +3639,18 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
                                       : launch_front_group<CS3_CHOLESKY>(D, g, inv_tol, s);
         });
         if (e != hipSuccess) return e;
+        if (ready_deferred && !rootf) {            // the level above the fork has been captured: now the side branch
+            if ((e = hipStreamWaitEvent(fj.aux, ready_deferred, 0)) != hipSuccess) return e;
+            if ((e = sweep(0, fork_level, fj.aux)) != hipSuccess) return e;
+            if ((e = fj.event(&swept)) != hipSuccess) return e;
+            if ((e = hipEventRecord(swept, fj.aux)) != hipSuccess) return e;
+            ready_deferred = nullptr;
+        }
         if (level == fork_level) {
             hipEvent_t ready;                      // panels of levels 0..fork_level are final
             if ((e = fj.event(&ready)) != hipSuccess) return e;
             if ((e = hipEventRecord(ready, st)) != hipSuccess) return e;
-            if (defer_sweep && rootf) { ready_deferred = ready; }
+            if (!sweep_first) { ready_deferred = ready; }      // captured after the chain above has begun (see the root's chain)
             else {
                 if ((e = hipStreamWaitEvent(fj.aux, ready, 0)) != hipSuccess) return e;
                 if ((e = sweep(0, fork_level, fj.aux)) != hipSuccess) return e;

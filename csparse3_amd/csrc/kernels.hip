@@ -590,8 +590,8 @@ __device__ __forceinline__ void eliminate32(double (&d)[BIG_NB], bool keep_unsca
 // NBK = pivots per block: 32, or 16 for a launch whose fronts have at most 16 pivots (the elimination runs all NBK
 // identity-padded steps).  The previous kernel for this class kept 5 x 9 register tiles and crossed the LDS and two block barriers for
 // every pivot (about 3 k cycles per pivot; this one: about 0.6 k).
-template <int KIND, int NBK>
-__global__ void __launch_bounds__(512)
+template <int KIND, int NBK, int NW = 8>
+__global__ void __launch_bounds__(NW * 64)
 k_front_block(const FrontDesc *__restrict__ fdesc, int first,
               const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
               const double *__restrict__ ax_all, double *__restrict__ pool_all,
@@ -617,11 +617,11 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
 
     // ---- assemble: F = sum of sources (A entries, children's contribution blocks)
     CS3_STAMP(0);
-    for (int i = tid; i < img + 1; i += 512) F[i] = 0.0;
+    for (int i = tid; i < img + 1; i += NW * 64) F[i] = 0.0;
     __syncthreads();
     CS3_STAMP(1);
     const float inv_ld = 1.0f / (float) ld;
-    gather_front<GATHER_UNROLL_WG>(d.asm_begin, d.asm_count >> 6, wv, 8, asm_src, asm_tgt, long_src,
+    gather_front<GATHER_UNROLL_WG>(d.asm_begin, d.asm_count >> 6, wv, NW, asm_src, asm_tgt, long_src,
                  [&](int q) -> const double * { return (q >= 0) ? ((q < il.len) ? pil + (long long) q * 64 : pool + q) : ax + ~q; },
                  [&](int t, double v) {
                      if (KIND == CS3_LU) { F[t] = v; return; }
@@ -692,7 +692,7 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
         // ---- 2. trailing update by MFMA, operands from the image: 16 x 16 tiles of F22 dealt to the 8 waves
         if (nrem > 0) {
             const int nt = (nrem + 15) / 16, mi = lane & 15, mq = lane >> 4;
-            for (int t = wv; t < nt * nt; t += 8) {
+            for (int t = wv; t < nt * nt; t += NW) {
                 const int ti = t % nt, tj = t / nt;             // tile rows ke + 16 ti.., columns ke + 16 tj..
                 if (KIND == CS3_CHOLESKY && ti < tj) continue;
                 const int i = ke + 16 * ti + mi;                // my row (B operand / output lanes % 16)
@@ -731,17 +731,17 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
     double *U = pool + d.upan;
     double *cb = pool + d.cb;
     const bool has_parent = d.parent >= 0;
-    for (int e = tid; e < r * w; e += 512) {                    // L panel, column-major r x w
+    for (int e = tid; e < r * w; e += NW * 64) {                    // L panel, column-major r x w
         const int i = e % r, j = e / r;
         if (KIND == CS3_LU || i >= j) L[e] = F[at(i, j)];
     }
     if (KIND == CS3_LU)
-        for (int e = tid; e < w * nb; e += 512) {               // U panel: pivot rows contiguous (u_sk = 1, u_sj = w)
+        for (int e = tid; e < w * nb; e += NW * 64) {               // U panel: pivot rows contiguous (u_sk = 1, u_sj = w)
             const int i = e % w, j = e / w;
             U[(long long) j * d.u_sj + (long long) i * d.u_sk] = F[i + (w + j) * ld];
         }
     if (has_parent)
-        for (int e = tid; e < nb * nb; e += 512) {
+        for (int e = tid; e < nb * nb; e += NW * 64) {
             const int i = e % nb, j = e / nb;
             if (KIND == CS3_LU || i >= j) cb[e] = F[at(w + i, w + j)];
         }
@@ -3090,7 +3090,12 @@ static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g
         static const int nbk = getenv("CS3_NBK") ? atoi(getenv("CS3_NBK")) : 16;
         // the image: r x (r | 1) for LU, the packed lower triangle for Cholesky, one zero entry behind it
         const size_t blds = ((KIND == CS3_LU) ? ld * (size_t) g.max_r : (size_t) g.max_r * (size_t) (g.max_r + 1) / 2) * sizeof(double) + 16;
-        if (nbk <= 8) hipLaunchKernelGGL((k_front_block<KIND, 8>), grid, dim3(512), blds, st, CS3_FRONT_ARGS);
+        // Cholesky has no block-row waves: four waves do all the eliminations of a block step, and a batch prefers more
+        // workgroups per CU to more waves per front (CS3_BLOCK_NW=8 restores eight)
+        static const int nw4 = !(getenv("CS3_BLOCK_NW") && atoi(getenv("CS3_BLOCK_NW")) == 8);
+        if (KIND == CS3_CHOLESKY && nw4 && D.batch >= 16 && nbk > 8 && nbk <= 16)
+            hipLaunchKernelGGL((k_front_block<CS3_CHOLESKY, 16, 4>), grid, dim3(256), blds, st, CS3_FRONT_ARGS);
+        else if (nbk <= 8) hipLaunchKernelGGL((k_front_block<KIND, 8>), grid, dim3(512), blds, st, CS3_FRONT_ARGS);
         else if (nbk <= 16) hipLaunchKernelGGL((k_front_block<KIND, 16>), grid, dim3(512), blds, st, CS3_FRONT_ARGS);
         else hipLaunchKernelGGL((k_front_block<KIND, 32>), grid, dim3(512), blds, st, CS3_FRONT_ARGS);
         break;
@@ -3108,6 +3113,7 @@ hipError_t prepare_kernels()
     const void *block_fns[] = {(const void *) k_front_block<CS3_LU, 16>, (const void *) k_front_block<CS3_LU, 32>,
                                (const void *) k_front_block<CS3_CHOLESKY, 16>, (const void *) k_front_block<CS3_CHOLESKY, 32>,
                                (const void *) k_front_block<CS3_LU, 8>, (const void *) k_front_block<CS3_CHOLESKY, 8>,
+                               (const void *) k_front_block<CS3_CHOLESKY, 16, 4>,
                                (const void *) k_front_wg<CS3_LU, 16>, (const void *) k_front_wg<CS3_CHOLESKY, 16>,
                                (const void *) k_front_wg<CS3_LU, 32>, (const void *) k_front_wg<CS3_CHOLESKY, 32>};
     for (const void *f : block_fns) {
@@ -3580,9 +3586,13 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
             // every fork the next launch of the block chain is captured BEFORE the side branch that hangs off the same
             // node: the chain stays in its queue, the late start lands on the sweep, which has slack.
             int k = 0;
-            while (k < pl.nchunk && (k + 1) * cwb <= nblk && nblk - (k + 1) * cwb >= k + 1) ++k;
+            // (one launch of slack: the side queue starts a chunk 10-15 us after its release)
+            while (k < pl.nchunk && (k + 1) * cwb <= nblk && nblk - (k + 1) * cwb >= k + 2) ++k;
             if (const char *rk = getenv("CS3_ROOT_K")) k = std::max(0, std::min(k, atoi(rk)));
-            static const bool absorb = !(getenv("CS3_NO_ABSORB") && getenv("CS3_NO_ABSORB")[0] == '1');
+            // CS3_ABSORB=1: the block chain waits for the side branch before the release launch, so that the released
+            // chunks hang off the chain alone (round 1's form: it paid while the chain hopped queues; with the chain in one
+            // queue the wait only stalls it -- 0.874 -> 0.868 ms per step without, same-box A/B x 3)
+            static const bool absorb = getenv("CS3_ABSORB") && getenv("CS3_ABSORB")[0] == '1';
             hipEvent_t home = nullptr;
             bool side_started = false;
             auto start_side = [&]() -> hipError_t {                        // sweep of the lower levels + the root's gather

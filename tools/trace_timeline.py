@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Timeline of ONE step from a rocprofv3 --kernel-trace CSV: per launch start (relative), duration and the gap to the
 previous launch on the same queue / to the latest end of any earlier launch.  Also sums by kernel.
-    python tools/trace_timeline.py <kernel_trace.csv> [--first KERNEL_SUBSTRING] [--skip N] [--out file.json]
+    python tools/trace_timeline.py <kernel_trace.csv> [--first KERNEL_SUBSTRING] [--skip N] [--fused] [--out file.json]
+--fused: the last FUSED factor + solve step (bench.py's timed step) rather than the last step of the trace.
 The step shown is the LAST one in the trace: it starts at the last launch whose name contains --first
 (default k_prologue; --skip N: the N-th from last, and later matches stay inside the step) and runs to the end of the
 trace or to the next non-cs3 kernel."""
@@ -11,18 +12,26 @@ path = sys.argv[1]
 first = "k_prologue"
 out = None
 skip = 0
+fused = False
 args = sys.argv[2:]
 while args:
     a = args.pop(0)
     if a == "--first": first = args.pop(0)
     elif a == "--out": out = args.pop(0)
     elif a == "--skip": skip = int(args.pop(0))
+    elif a == "--fused": fused = True
 rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: r["Kernel_Name"].split("(")[0].replace("void ", "").replace("cs3::", "")
 starts = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
 if not starts:
     sys.exit("no launch matching %r" % first)
 i0 = starts[-1 - skip]
+if fused:            # the last step that holds backward-sweep launches and no stand-alone copy of the right-hand sides
+    bounds = starts + [len(rows)]
+    for a0, b0 in zip(bounds[:-1], bounds[1:]):
+        seg = [r["Kernel_Name"] for r in rows[a0:b0]]
+        if any("k_bwd" in n for n in seg) and not any("copyBuffer" in n for n in seg):
+            i0 = a0
 i1 = i0
 allowed = skip
 while i1 + 1 < len(rows) and ("cs3::" in rows[i1 + 1]["Kernel_Name"] or "__amd_rocclr" in rows[i1 + 1]["Kernel_Name"]):

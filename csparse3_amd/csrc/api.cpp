@@ -155,7 +155,7 @@ int ensure_device_impl(cs3_handle h)
         f.bv = S.bv_off[s];
         f.gv = S.gv_off[s]; f.dinv = S.dinv_off[s];
         f.rl_begin = S.rl_ptr[s]; f.rl_count = (int) (S.rl_ptr[s + 1] - S.rl_ptr[s]);
-        if (S.sn_class[s] != FC_IL) { f.rl_begin = S.sl_ptr[s]; f.rl_count = S.sl_rounds[s]; }
+        if (S.sn_class[s] != FC_IL && !S.sn_il_panels[s]) { f.rl_begin = S.sl_ptr[s]; f.rl_count = S.sl_rounds[s]; }   // not a lane = matrix sweep
         f.c0 = S.sn_ptr[s];
         f.r = (int) (S.st_ptr[s + 1] - S.st_ptr[s]);
         f.w = S.sn_ptr[s + 1] - S.sn_ptr[s];

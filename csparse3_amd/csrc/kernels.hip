@@ -339,11 +339,14 @@ front_wave_body(const FrontDesc &d, int first, double *F,
                 long long nnz_a, long long pool_stride, IlView il, double inv_tol, int *status, long long *tbuf, long long t_start)
 {
 #define CS3_STAMP(p) do { if (tbuf && threadIdx.x == 0) tbuf[(long long) (first + blockIdx.x) * 8 + (p)] = (long long) __builtin_amdgcn_s_memtime() - t_start; } while (0)
-    const double *pil = il_lane_base(il, blockIdx.y);
+    double *pil = il_lane_base(il, blockIdx.y);
     const double *ax = ax_all + (long long) blockIdx.y * nnz_a;
     double *pool = pool_all + (long long) blockIdx.y * pool_stride;
     const int r = d.r, w = d.w, nb = r - w;
     const int ld = r | 1;
+    // a pool offset below il.len lives in the matrix-interleaved region (the panels of a front whose sweeps run lane =
+    // matrix): entry `off` of this matrix is pil[off * 64]
+    auto home = [&](int off) -> double * { return (off < il.len) ? pil + (long long) off * 64 : pool + off; };
     // four waves assemble the front (the gather is latency-bound: more loads in flight), one eliminates it
     CS3_STAMP(0);
     const int nwaves = blockDim.x >> 6;
@@ -437,7 +440,7 @@ front_wave_body(const FrontDesc &d, int first, double *F,
                 bad = bad | rej;
                 const int off = in_l ? lp + j * r : base2 + j * stride2;
                 const bool ok = (in_l ? live : ok2) & tri;
-                if (ok) pool[off] = v;
+                if (ok) *home(off) = v;
             }
         }
     }
@@ -464,9 +467,9 @@ front_wave_body(const FrontDesc &d, int first, double *F,
                     rej = (i == j) & !(v > 0.0);
                 }
                 if (rej && (!bad || j < bad_col)) { bad = true; bad_col = j; }
-                if (tri) pool[(int) d.lpan + i + j * r] = v;
+                if (tri) *home((int) d.lpan + i + j * r) = v;
             } else if (i < w) {
-                if (KIND == CS3_LU) pool[(int) d.upan + i * d.u_sk + (j - w) * d.u_sj] = v;
+                if (KIND == CS3_LU) *home((int) d.upan + i * d.u_sk + (j - w) * d.u_sj) = v;
             } else if (has_parent && tri) {
                 pool[(int) d.cb + (i - w) + (j - w) * nb] = v;
             }
@@ -2273,12 +2276,14 @@ k_front_il(const FrontDesc *__restrict__ fdesc, int first, const int *__restrict
 }
 
 // Sweeps of the interleaved fronts, lane = matrix.  The front vector of every matrix sits in LDS (one column per
-// lane: conflict-free) and the recurrences run as plain dynamic loops -- one coalesced 512-byte load of a panel
-// entry (different in every lane), one LDS read-modify-write and one FMA per factor entry; nothing is unrolled over
-// the front, so the kernels stay small at full occupancy.  X and the contribution vectors stay per-matrix (a few
-// values per front: strided over the lanes).  RMAX bounds the front order (LDS: RMAX * 512 bytes per wave).
+// lane: conflict-free); X and the contribution vectors stay per-matrix (a few values per front: strided over the
+// lanes).  A wave is alone with its 64 matrices, so what it waits for is memory latency: both sweeps make ONE pass of w
+// steps over the panel (w = pivots of the front), and the panel entries of step k + 1 -- a column of L forward, a row of
+// U (Cholesky: a column of L again) backward, 512 coalesced bytes per entry -- are in flight while step k computes.
+// (Round 2a walked the backward sweep by columns: r steps, each waiting for its own loads -- 68 us for one front of
+// order 30.)  RMAX bounds the front order (LDS: RMAX * 512 bytes per wave).
 template <int KIND, int RMAX>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, (RMAX <= 16) ? 3 : 2)
 k_fwd_il(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ rl, IlView il,
          double *cv_all, double *X_all, int nrhs, long long cv_stride, long long x_stride, int batch)
 {
@@ -2323,12 +2328,38 @@ k_fwd_il(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ rl
             }
             if (cur >= 0) v[cur * 64] += acc;
         }
-        for (int k = 0; k < w; ++k) {
+        // two register buffers, two columns per trip: while column k updates the vector, column k + 1 is in flight
+        double ca[RMAX + 1], cb[RMAX + 1];                         // (+ 1: a power-of-two array becomes a vector value, see k_fwd_rhs)
+        auto fetch = [&](int k, double (&c)[RMAX + 1]) {           // rows k .. r - 1 of column k (the diagonal included)
             const double *Lk = L + (long long) k * r * 64;
-            double vk = v[k * 64];
-            if (KIND == CS3_CHOLESKY) { vk *= fast_rcp(Lk[k * 64]); v[k * 64] = vk; }
-#pragma unroll 8
-            for (int i = k + 1; i < r; ++i) v[i * 64] -= Lk[i * 64] * vk;
+#pragma unroll
+            for (int i = 0; i < RMAX; ++i) { c[i] = 1.0; if (i >= k && i < r && k < w) c[i] = Lk[(long long) i * 64]; }
+        };
+        auto apply = [&](int k, const double (&c)[RMAX + 1]) {
+            double vk = v[k * 64], dg = 1.0;
+            if (KIND == CS3_CHOLESKY) {
+#pragma unroll
+                for (int i = 0; i < RMAX; ++i) if (i == k) dg = c[i];
+                vk *= fast_rcp(dg); v[k * 64] = vk;
+            }
+#pragma unroll
+            for (int i0 = 0; i0 < RMAX; i0 += 8) {
+                if (i0 + 8 > k + 1 && i0 < r) {                      // groups of 8 rows: at most 8 LDS values in flight
+#pragma unroll
+                    for (int i = i0; i < i0 + 8; ++i)
+                        if (i > k && i < r) v[i * 64] -= c[i] * vk;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        fetch(0, ca);
+        for (int k = 0; k < w; k += 2) {
+            fetch(k + 1, cb);
+            apply(k, ca);
+            if (k + 1 < w) {
+                fetch(k + 2, ca);
+                apply(k + 1, cb);
+            }
         }
         if (live) {
 #pragma unroll 8
@@ -2340,7 +2371,7 @@ k_fwd_il(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ rl
 }
 
 template <int KIND, int RMAX>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, (RMAX <= 16) ? 4 : 2)
 k_bwd_il(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ st_idx, IlView il,
          double *X_all, int nrhs, long long x_stride, int batch)
 {
@@ -2356,18 +2387,34 @@ k_bwd_il(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ st
     double *x = xl + lane;
     // row of X behind front position `lane` (the same for every matrix)
     const int myrow = (lane < w) ? d.c0 + lane : st_idx[d.st + (lane < r ? lane : 0)];
+    // row i of M = [U11 U12] (Cholesky: [L11' L21'], i.e. column i of L): M(i, t) at L[(i + t r) 64] (Cholesky: (t + i r) 64)
+    const long long ms = (KIND == CS3_LU) ? (long long) r * 64 : 64;
+    auto row_of = [&](int i) -> const double * { return (KIND == CS3_LU) ? L + (long long) i * 64 : L + (long long) i * r * 64; };
     for (int q = 0; q < nrhs; ++q) {
+        double rowv[RMAX + 1], nxt[RMAX + 1];              // (+ 1: see k_fwd_rhs)
+        {   // the last pivot row goes out first
+            const double *M = row_of(w - 1);
+#pragma unroll
+            for (int t = 0; t < RMAX; ++t) { rowv[t] = 0.0; if (t >= w - 1 && t < r) rowv[t] = M[(long long) t * ms]; }
+        }
 #pragma unroll 8
         for (int t = 0; t < r; ++t) x[t * 64] = X[(long long) bcast_lane_i(myrow, t) * nrhs + q];
-        for (int t = r - 1; t >= 0; --t) {
-            double xt = x[t * 64];
-            if (t < w) { xt *= fast_rcp(L[((long long) t + (long long) t * r) * 64]); x[t * 64] = xt; }
-            const int top = min(t, w);                              // rows below w are the ancestors' (final) values
-            // M(i, t): U(i, t) = element (i, t); Cholesky: L(t, i) = element (t, i)
-            const double *Mt = (KIND == CS3_LU) ? L + (long long) t * r * 64 : L + (long long) t * 64;
-            const long long ms = (KIND == CS3_LU) ? 64 : (long long) r * 64;
-#pragma unroll 8
-            for (int i = 0; i < top; ++i) x[i * 64] -= Mt[i * ms] * xt;
+        for (int i = w - 1; i >= 0; --i) {
+            if (i > 0) {                                            // row i - 1: its diagonal and everything to the right
+                const double *M = row_of(i - 1);
+#pragma unroll
+                for (int t = 0; t < RMAX; ++t) { nxt[t] = 0.0; if (t >= i - 1 && t < r) nxt[t] = M[(long long) t * ms]; }
+            }
+            // x_i = (x_i - sum_{t > i} M(i, t) x_t) / M(i, i): the x_t are final (pivot rows done above, ancestors' rows given)
+            double acc = x[i * 64], dg = 1.0;
+#pragma unroll
+            for (int t = 0; t < RMAX; ++t) {
+                if (t == i) dg = rowv[t];
+                if (t > i && t < r) acc -= rowv[t] * x[t * 64];
+            }
+            x[i * 64] = acc * fast_rcp(dg);
+#pragma unroll
+            for (int t = 0; t < RMAX; ++t) rowv[t] = nxt[t];
         }
         if (live) {
 #pragma unroll 8
@@ -3399,13 +3446,28 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
     if (use_gemm && nrhs >= RHS_LANES_MIN && (g.cls == SK_WAVE || g.cls == SK_BLOCK || g.cls == SK_BIG))
         return launch_gemm_group<KIND>(D, g, X, nrhs, forward, forward && D.inverses_in_sweep, st);
     if (g.cls == SK_IL) {
-        dim3 grid((unsigned) g.count, (unsigned) D.ngroups);
-        if (forward)
-            hipLaunchKernelGGL((k_fwd_il<KIND, IL_RMAX>), grid, dim3(64), 0, st, D.sdesc, g.first, D.rl_pairs,
-                               IlView{D.pool_il, D.il_len}, D.cv, X, nrhs, cvs, xs, (int) D.batch);
-        else
-            hipLaunchKernelGGL((k_bwd_il<KIND, IL_RMAX>), grid, dim3(64), 0, st, D.sdesc, g.first, D.st_idx,
-                               IlView{D.pool_il, D.il_len}, X, nrhs, xs, (int) D.batch);
+        // the fronts of order <= 16 come first in the group: half the LDS per wave (the front vector of 64 matrices),
+        // twice the waves per CU -- these sweeps wait on one round trip per pivot
+        static const bool il16 = !(getenv("CS3_NO_IL16") && getenv("CS3_NO_IL16")[0] == '1');
+        const int n16 = il16 ? g.n16 : 0;
+        if (n16 > 0) {
+            dim3 grid((unsigned) n16, (unsigned) D.ngroups);
+            if (forward)
+                hipLaunchKernelGGL((k_fwd_il<KIND, 16>), grid, dim3(64), 0, st, D.sdesc, g.first, D.rl_pairs,
+                                   IlView{D.pool_il, D.il_len}, D.cv, X, nrhs, cvs, xs, (int) D.batch);
+            else
+                hipLaunchKernelGGL((k_bwd_il<KIND, 16>), grid, dim3(64), 0, st, D.sdesc, g.first, D.st_idx,
+                                   IlView{D.pool_il, D.il_len}, X, nrhs, xs, (int) D.batch);
+        }
+        if (g.count > n16) {
+            dim3 grid((unsigned) (g.count - n16), (unsigned) D.ngroups);
+            if (forward)
+                hipLaunchKernelGGL((k_fwd_il<KIND, IL_RMAX>), grid, dim3(64), 0, st, D.sdesc, g.first + n16, D.rl_pairs,
+                                   IlView{D.pool_il, D.il_len}, D.cv, X, nrhs, cvs, xs, (int) D.batch);
+            else
+                hipLaunchKernelGGL((k_bwd_il<KIND, IL_RMAX>), grid, dim3(64), 0, st, D.sdesc, g.first + n16, D.st_idx,
+                                   IlView{D.pool_il, D.il_len}, X, nrhs, xs, (int) D.batch);
+        }
     } else if (g.cls == SK_SMALL && nrhs >= RHS_LANES_MIN) {
         // the fronts of order <= 16 come first in the group: half the registers per wave, twice the waves per CU
         // (these sweeps are bound by memory latency times occupancy); the two launches are independent

@@ -115,6 +115,18 @@ i64 il_rmax()
     return v;
 }
 
+// Interleaved batches: fronts of order il_rmax() < r <= il_sweep_rmax() keep their lane = row factor kernel but store
+// their PANELS in the interleaved region, so that the sweeps of these fronts run lane = matrix as well (panels streamed
+// at memory rate, no index lists) -- the lane = row sweeps spend 60 % of their wave cycles parked on round trips.
+// OFF by default (CS3_IL_SWEEP_RMAX=32 turns it on): measured 3.91 against 3.87 ms on 512 matrices -- the backward sweeps
+// gain 90 us, but a level with few such fronts has only batch / 64 waves per front and the forward assembly (strided
+// contribution vectors) is no faster lane = matrix.
+i64 il_sweep_rmax()
+{
+    static const i64 v = [] { const char *e = std::getenv("CS3_IL_SWEEP_RMAX"); i64 x = e ? std::atoll(e) : 0; return std::min<i64>(std::max<i64>(x, 0), IL_RMAX); }();
+    return v;
+}
+
 int front_class(i64 r, i64 w, bool split_small, bool interleave)
 {
     if (r <= il_rmax() && interleave) return FC_IL;   // batches of 64 or more: lane = matrix on the interleaved region
@@ -307,7 +319,11 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     //          whose columns end where its own begin) when that adds few explicit
     //          zeros.  Every dependent launch costs microseconds on the device,
     //          so a shallower tree is worth far more than the padded flops.
-    double relax_z = 0.5; i64 relax_w = 8;
+    //          A batch of 64 or more matrices fills the chip at every level and runs its fronts of order <= 16 lane =
+    //          matrix, ten times cheaper per front than the lane = row kernels above them: there a merge must earn more
+    //          (measured on 512 x 5000^2: 3.83 -> 3.62 ms; 128 x 20000^2: 10.4 -> 7.5 ms; 512 x 3000^2: 2.02 -> 1.83 ms).
+    const bool batch_economy = S.batch >= 64;
+    double relax_z = batch_economy ? 0.25 : 0.5; i64 relax_w = batch_economy ? 4 : 8;
     if (const char *e = std::getenv("CS3_RELAX_Z")) relax_z = std::atof(e);
     if (const char *e = std::getenv("CS3_RELAX_W")) relax_w = std::atoll(e);
     i64 relax_r = 32; double relax_z2 = 0.25;          // fronts beyond the one-wave kernels (r > 32) merge only when nearly free
@@ -411,6 +427,15 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         S.cb_off[s] = voff + w + w * r; S.cb_ld[s] = (i32) r;
         voff += r * r;
     }
+    S.sn_il_panels.assign(ns, 0);
+    for (i32 s = 0; s < ns && interleave; ++s) {     // ... then the panels of the lane = row fronts that sweep lane = matrix
+        const i64 w = width(s), r = order_r(s);
+        if (front_class(r, w, S.batch >= 8, interleave) != FC_R32 || r > il_sweep_rmax()) continue;
+        S.sn_il_panels[s] = 1;
+        S.lpan_off[s] = voff;                        // dense addressing (i, j) -> i + j r like the FC_IL fronts: L in the
+        if (kind == CS3_LU) { S.upan_off[s] = voff + w * r; S.u_sk[s] = 1; S.u_sj[s] = (i32) r; }     // first w columns, U12
+        voff += (kind == CS3_LU) ? r * r : r * w;    // in rows < w of the others (the block below it stays unused)
+    }
     S.il_len = voff;
     for (i32 s = 0; s < ns; ++s) {                   // panels of the LDS-resident fronts
         const i64 w = width(s), r = order_r(s), nb = r - w;
@@ -423,7 +448,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
             double m = (double) (r - k - 1);
             S.flops += (kind == CS3_LU) ? (m + 2.0 * m * m) : (m + m * (m + 1.0) + 1.0);
         }
-        if (S.sn_class[s] == FC_BIG || S.sn_class[s] == FC_IL) continue;
+        if (S.sn_class[s] == FC_BIG || S.sn_class[s] == FC_IL || S.sn_il_panels[s]) continue;
         S.lpan_off[s] = voff; voff += r * w;
         // U panel w x nb, pivot rows contiguous: a wave whose lanes are rows stores and reads it coalesced
         if (kind == CS3_LU) { S.upan_off[s] = voff; voff += nb * w; S.u_sk[s] = 1; S.u_sj[s] = (i32) w; }
@@ -629,7 +654,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     // pairs per lane (one wave per SIMD) and measured 45 us per level on a handful of fronts, the GEMM pair 19.
     static const i64 small_rmax = std::getenv("CS3_RHS_LANES_RMAX") ? std::atoll(std::getenv("CS3_RHS_LANES_RMAX")) : 32;
     auto solve_kind = [&](i32 s) {
-        if (S.sn_class[s] == FC_IL) return (int) SK_IL;
+        if (S.sn_class[s] == FC_IL || S.sn_il_panels[s]) return (int) SK_IL;
         if (order_r(s) <= small_rmax) return (int) SK_SMALL;
         if (order_r(s) <= 128 && width(s) <= 64) return (int) SK_WAVE;
         // wide big fronts: one launch per chunk with many workgroups for a lone matrix; a batch fills the chip with one

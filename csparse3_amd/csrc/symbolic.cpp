@@ -323,7 +323,9 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     //          matrix, ten times cheaper per front than the lane = row kernels above them: there a merge must earn more
     //          (measured on 512 x 5000^2: 3.83 -> 3.62 ms; 128 x 20000^2: 10.4 -> 7.5 ms; 512 x 3000^2: 2.02 -> 1.83 ms).
     const bool batch_economy = S.batch >= 64;
-    double relax_z = batch_economy ? 0.25 : 0.5; i64 relax_w = batch_economy ? 4 : 8;
+    // (single matrices: 0.7 since round 2 -- re-measured with this round's kernels: 50k 0.871 -> 0.829 ms, 10k 0.57 -> 0.48,
+    //  20k 0.75 -> 0.71, 100k equal, 200k 2.76 -> 2.62; the 0.5 of round 1 had been set with slower block-front kernels)
+    double relax_z = batch_economy ? 0.25 : 0.7; i64 relax_w = batch_economy ? 4 : 8;
     if (const char *e = std::getenv("CS3_RELAX_Z")) relax_z = std::atof(e);
     if (const char *e = std::getenv("CS3_RELAX_W")) relax_w = std::atoll(e);
     i64 relax_r = 32; double relax_z2 = 0.25;          // fronts beyond the one-wave kernels (r > 32) merge only when nearly free

@@ -867,35 +867,63 @@ k_front_wg(const FrontDesc *__restrict__ fdesc, int first,
         }
         __syncthreads();
         if (prof) { const long long now = (long long) __builtin_amdgcn_s_memtime(); t_panel += now - t_mark; t_mark = now; }
-        // ---- 2. trailing update by MFMA: 16 x 16 tiles of F22 dealt to the 8 waves, operands from the LDS panels
+        // ---- 2. trailing update by MFMA: 16 x 16 tiles of F22 dealt to the 8 waves, operands from the LDS panels.  The
+        // tiles that exist (Cholesky: the lower ones) are numbered 0 .. ntile - 1 and a wave takes TU of them per pass: their
+        // accumulator loads go out together, so a pass costs one round trip to the buffer instead of TU
         if (nrem > 0) {
+            constexpr int TU = 3;
             const int nt = (nrem + 15) / 16, mi = lane & 15, mq = lane >> 4;
+            const int ntile = (KIND == CS3_LU) ? nt * nt : nt * (nt + 1) / 2;
             const double *Ua = (KIND == CS3_LU) ? Up : Lp;
-            for (int t = wv; t < nt * nt; t += 8) {
-                const int ti = t % nt, tj = t / nt;             // tile rows ke + 16 ti.., columns ke + 16 tj..
-                if (KIND == CS3_CHOLESKY && ti < tj) continue;
-                const int ia = 16 * ti + mi, ca = 16 * tj + mi; // panel-local row (B operand / output lanes) and column (A operand)
-                const int i = ke + ia;
-                double4_t acc;
+            for (int u0 = wv; u0 < ntile; u0 += 8 * TU) {
+                int ti[TU], tj[TU];
+                bool on[TU];
+                double4_t acc[TU];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int c = ke + 16 * tj + mq + 4 * v;
-                    acc[v] = load_if(F, i + (long long) c * ld, i < r && c < r);
-                }
-#pragma unroll
-                for (int k0 = 0; k0 < NB; k0 += 4) {
-                    if (k0 < bw) {
-                        const int k = k0 + mq;
-                        const bool kin = k < bw;
-                        const double au = (kin && ca < nrem) ? Ua[k * pld + ca] : 0.0;
-                        const double bl = (kin && ia < nrem) ? -Lp[k * pld + ia] : 0.0;
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(au, bl, acc, 0, 0, 0);
+                for (int q = 0; q < TU; ++q) {
+                    int u = u0 + 8 * q;
+                    on[q] = u < ntile;
+                    if (!on[q]) u = 0;
+                    if (KIND == CS3_LU) { ti[q] = u % nt; tj[q] = u / nt; }
+                    else {                                      // column tj holds the tiles tj .. nt - 1
+                        int c = 0;
+                        while (u >= nt - c) { u -= nt - c; ++c; }
+                        tj[q] = c; ti[q] = c + u;
                     }
                 }
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int c = ke + 16 * tj + mq + 4 * v;
-                    if (i < r && c < r) F[i + (long long) c * ld] = acc[v];
+                for (int q = 0; q < TU; ++q) {
+                    const int i = ke + 16 * ti[q] + mi;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int c = ke + 16 * tj[q] + mq + 4 * v;
+                        acc[q][v] = load_if(F, i + (long long) c * ld, on[q] && i < r && c < r);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < TU; ++q) {
+                    if (!on[q]) continue;                       // wave-uniform
+                    const int ia = 16 * ti[q] + mi, ca = 16 * tj[q] + mi;   // panel-local row (B operand / output lanes), column (A operand)
+#pragma unroll
+                    for (int k0 = 0; k0 < NB; k0 += 4) {
+                        if (k0 < bw) {
+                            const int k = k0 + mq;
+                            const bool kin = k < bw;
+                            const double au = (kin && ca < nrem) ? Ua[k * pld + ca] : 0.0;
+                            const double bl = (kin && ia < nrem) ? -Lp[k * pld + ia] : 0.0;
+                            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(au, bl, acc[q], 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < TU; ++q) {
+                    if (!on[q]) continue;
+                    const int i = ke + 16 * ti[q] + mi;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int c = ke + 16 * tj[q] + mq + 4 * v;
+                        if (i < r && c < r) F[i + (long long) c * ld] = acc[q][v];
+                    }
                 }
             }
         }

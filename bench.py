@@ -195,6 +195,19 @@ def leg_config4(args, dist, rank, world, dev, comm_dev, host_baseline):
     keys = ["factor", "broadcast", "scatter", "solve", "gather", "total"]
     med = [float(np.median([p.get(kk, 0.0) for p in phases])) for kk in keys]
     med = _max_over_ranks(dist, world, comm_dev, med)
+    # one GPU: the same sweep bracketed by HIP events on the launch stream (the phase above is host wall-clock between
+    # two device synchronisations: it carries the graph launch and the wake-up of the host, 50-90 us)
+    solve_ms_events = None
+    if world == 1:
+        sh = torch.cuda.current_stream().cuda_stream
+        Xe = torch.empty_like(Bd)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in evs:
+            Xe.copy_(Bd)
+            a.record(); be.F.solve_dev(Xe.data_ptr(), k, sh); b.record()
+        torch.cuda.synchronize()
+        solve_ms_events = float(np.median([a.elapsed_time(b) for a, b in evs]))
+        del Xe
     out = None
     if rank == 0:
         x0 = X[:, 0].cpu().numpy()
@@ -217,6 +230,9 @@ def leg_config4(args, dist, rank, world, dev, comm_dev, host_baseline):
                "frac_note": "solve phase: algorithmic bytes / max-over-ranks solve time / (n_gpus x 8 TB/s)",
                "factor_bytes_broadcast": int(info.factor_bytes),
                "rel_residual": rel}
+        if solve_ms_events is not None:
+            out["solve_ms_events"] = solve_ms_events
+            out["frac_events"] = bytes_solve / (1e-3 * solve_ms_events) / 1e9 / HBM_PEAK_GBS
         if host_baseline:
             try:
                 from oracle import oracle as orc

@@ -435,6 +435,80 @@ def test_config5_slice_full_size_properties(gpu, orc):
     assert rel_err(X[37], x1) <= 1e-12
 
 
+def test_config4_at_its_own_size_one_gpu(gpu, orc):
+    """BASELINE configs[3] whole on one GPU: the 50k matrix, factor once, 1024 right-hand sides resident in HBM --
+    the shape `bench.py`'s config-4 leg runs (fused permutations, GEMM sweeps, lane = right-hand-side sweeps).
+    Residual of every column, bitwise run-to-run, agreement with the 1-RHS and 128-RHS paths, oracle parity of
+    three columns."""
+    import torch
+    m, n, Ap, Ai, Ax = synth.grid_jacobian()
+    A = csc_to_scipy(m, n, Ap, Ai, Ax)
+    k = 1024
+    B = synth.grid_rhs(n, k, seed=1024)
+    dev = torch.device("cuda", 0)
+    sh = torch.cuda.current_stream().cuda_stream
+    with gpu.Factorization(m, n, Ap, Ai) as F:
+        F.factor(Ax, 1e-3)
+        d_b = torch.from_numpy(B).to(dev)
+        d_x = d_b.clone()
+        F.solve_dev(d_x.data_ptr(), k, sh)
+        d_x2 = d_b.clone()
+        F.solve_dev(d_x2.data_ptr(), k, sh)
+        torch.cuda.synchronize()
+        assert torch.equal(d_x, d_x2)                                       # no float atomics anywhere
+        X = d_x.cpu().numpy()
+        x5 = F.solve(np.ascontiguousarray(B[:, 5]))
+        X128 = F.solve(np.ascontiguousarray(B[:, 896:]))
+        Lp, Li, Lx, Up, Ui, Ux = F.factors()
+        o = F.ordering()
+    scale = abs(A).sum(axis=0).max()
+    for c0 in range(0, k, 256):                                             # residual of every column, 256 at a time
+        R = A @ X[:, c0:c0 + 256] - B[:, c0:c0 + 256]
+        assert np.abs(R).max() <= 1e-13 * (scale * np.abs(X).max() + np.abs(B).max())
+    assert rel_err(X[:, 5], x5) <= 1e-12
+    assert rel_err(X[:, 896:], X128) <= 1e-12
+    for j in (0, 511, 1023):
+        w = np.empty(n); w[o["pinv"]] = B[:, j]
+        orc.csc_lsolve_f(n, Lp, Li, Lx, w)
+        orc.csc_usolve_f(n, Up, Ui, Ux, w)
+        want = np.empty(n); want[o["q"]] = w
+        assert rel_err(X[:, j], want) <= RTOL
+
+
+def test_config5_at_its_own_size_one_gpu(gpu, orc):
+    """BASELINE configs[4] whole on one GPU: 512 SPD 5k x 5k matrices sharing a pattern, Cholesky factor + one solve
+    each through the fused call (eight groups of 64 matrices on the interleaved region).  Fused == factor-then-solve
+    bit for bit, residual of every matrix, three matrices against the oracle."""
+    import torch
+    n5, nmat = 5000, 512
+    ei, ej = synth.spd_grid_pattern(n5, seed=5000)
+    m, n, Ap, Ai, _ = synth.spd_grid_matrix(n5, ei, ej, seed=5000)
+    AX = np.stack([synth.spd_grid_matrix(n5, ei, ej, seed=5000 + i)[4] for i in range(nmat)])
+    B = np.random.default_rng(0).standard_normal((nmat, n, 1))
+    dev = torch.device("cuda", 0)
+    sh = torch.cuda.current_stream().cuda_stream
+    with gpu.Factorization(m, n, Ap, Ai, kind=gpu.CS3_CHOLESKY, batch=nmat) as F:
+        d_ax = torch.from_numpy(AX).to(dev)
+        d_x = torch.from_numpy(B.copy()).to(dev)
+        F.factor_solve_dev(d_ax.data_ptr(), d_x.data_ptr(), 1, 0.0, sh)
+        F.factor_status(sh)
+        d_x2 = torch.from_numpy(B.copy()).to(dev)
+        F.factor_dev(d_ax.data_ptr(), 0.0, sh)
+        F.solve_dev(d_x2.data_ptr(), 1, sh)
+        F.factor_status(sh)
+        assert torch.equal(d_x, d_x2)
+        X = d_x.cpu().numpy()
+        q = F.ordering()["q"]
+        fac = {i: F.factors(b=i) for i in (0, 300, 511)}
+    import scipy.sparse as sp
+    Aall = [csc_to_scipy(m, n, Ap, Ai, AX[i]) for i in range(nmat)]
+    for i in range(nmat):
+        r = np.abs(Aall[i] @ X[i, :, 0] - B[i, :, 0]).max()
+        assert r <= 1e-12 * (abs(Aall[i]).sum(axis=0).max() * np.abs(X[i]).max() + np.abs(B[i]).max()), (i, r)
+    for i, (Lp, Li, Lx, _, _, _) in fac.items():
+        assert_factor_equal(n, (Lp, Li, Lx), _oracle_chol(orc, n, Ap, Ai, AX[i], q), "config-5 matrix %d" % i)
+
+
 # ------------------------------------------------------------- edge cases ----
 
 def _arrow_with_dense_row(n=400, seed=0):

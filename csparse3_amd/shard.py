@@ -133,7 +133,9 @@ def solve_many_rhs(backend, Ax, B, tol=0.0, group=None, root=0, timings=None, sy
         ph.mark("factor")
         fac = backend.empty_factor()
     if world > 1:
+        _settle(fac, group)
         dist.broadcast(fac, src=root, group=group)
+        _settle(fac, group)
         if rank != root:
             backend.import_factor(fac)
     ph.mark("broadcast")
@@ -221,6 +223,15 @@ def _comm_device(backend):
     return dev if dev is not None else torch.device("cpu")
 
 
+def _settle(t, group):
+    """RCCL orders a collective with the caller's stream on both sides.  Other backends (gloo: the one-GPU rehearsal)
+    move device tensors through host copies on streams of their own, which neither wait for kernels queued on the
+    caller's stream nor are waited for by it -- a slab could leave before its sweep had run, or land after it.  So
+    around every transfer of a device tensor they get a device-wide synchronisation; RCCL gets none."""
+    if t is not None and t.is_cuda and dist.get_backend(group) != "nccl":
+        torch.cuda.synchronize(t.device)
+
+
 def _scatter_uneven(recv, slabs, root, group):
     """Fan-out from root as ONE batch of point-to-point sends (slabs may differ in width, so no scatter collective;
     batched, RCCL drives all of the root's xGMI links at once instead of one peer after the other)."""
@@ -234,9 +245,11 @@ def _scatter_uneven(recv, slabs, root, group):
                 ops.append(dist.P2POp(dist.isend, slabs[r], r, group))
     elif recv.numel() > 0:
         ops.append(dist.P2POp(dist.irecv, recv, root, group))
+    _settle(recv, group)
     if ops:
         for q in dist.batch_isend_irecv(ops):
             q.wait()
+    _settle(recv, group)
 
 
 def _gather_uneven(send, shapes, root, group):
@@ -254,7 +267,9 @@ def _gather_uneven(send, shapes, root, group):
                 ops.append(dist.P2POp(dist.irecv, t, r, group))
     elif send.numel() > 0:
         ops.append(dist.P2POp(dist.isend, send, root, group))
+    _settle(send, group)
     if ops:
         for q in dist.batch_isend_irecv(ops):
             q.wait()
+    _settle(send, group)
     return out

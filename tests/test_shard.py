@@ -132,6 +132,63 @@ def test_two_ranks_gloo(tmp_path, mode):
             assert np.abs(A @ X[i] - B[i]).max() <= 1e-10
 
 
+def _gpu_worker(rank, world, port, mode, out):
+    """Two ranks sharing cuda:0, collectives over gloo: the N > 1 code path of bench.py's sharding legs with the REAL
+    backend (factor export -> broadcast -> import, RHS slabs, matrix slices)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        if mode == "rhs":
+            m, n, Ap, Ai, Ax = synth.grid_jacobian(n=3000, seed=3)
+            B = np.random.default_rng(0).standard_normal((n, 37))         # 37 columns over 2 ranks: 19 + 18 (lane = RHS path)
+            be = shard.HipBackend(m, n, Ap, Ai, device=dev)
+            X = shard.solve_many_rhs(be, Ax if rank == 0 else None, B if rank == 0 else None, tol=1e-3)
+            if rank == 0:
+                np.save(out, X.cpu().numpy())
+        else:
+            n = 1200
+            ei, ej = synth.spd_grid_pattern(n, seed=5)
+            m, n, Ap, Ai, _ = synth.spd_grid_matrix(n, ei, ej, seed=50)
+            AX = np.stack([synth.spd_grid_matrix(n, ei, ej, seed=50 + i)[4] for i in range(5)])
+            B = np.random.default_rng(1).standard_normal((5, n, 2))
+            from csparse3_amd import csc_hip
+            X = shard.solve_many_matrices(lambda b: shard.HipBackend(m, n, Ap, Ai, kind=csc_hip.CS3_CHOLESKY, batch=b, device=dev),
+                                          AX, B, tol=0.0)
+            if rank == 0:
+                np.save(out, X.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["rhs", "matrices"])
+def test_two_ranks_gloo_on_one_gpu(gpu, tmp_path, mode):
+    import scipy.sparse as sp
+    out = str(tmp_path / "x.npy")
+    mp.spawn(_gpu_worker, args=(2, _free_port(), mode, out), nprocs=2, join=True)
+    X = np.load(out)
+    if mode == "rhs":
+        m, n, Ap, Ai, Ax = synth.grid_jacobian(n=3000, seed=3)
+        B = np.random.default_rng(0).standard_normal((n, 37))
+        A = sp.csc_matrix((Ax, Ai, Ap), shape=(n, n))
+        assert X.shape == (n, 37)
+        assert np.abs(A @ X - B).max() <= 1e-10 * np.abs(B).max()
+        with gpu.Factorization(m, n, Ap, Ai) as F:                          # the same through one handle
+            F.factor(Ax, 1e-3)
+            assert np.abs(X - F.solve(B)).max() <= 1e-12 * np.abs(X).max()
+    else:
+        n = 1200
+        ei, ej = synth.spd_grid_pattern(n, seed=5)
+        B = np.random.default_rng(1).standard_normal((5, n, 2))
+        assert X.shape == (5, n, 2)
+        for i in range(5):
+            m, n, Ap, Ai, Ax = synth.spd_grid_matrix(n, ei, ej, seed=50 + i)
+            A = sp.csc_matrix((Ax, Ai, Ap), shape=(n, n))
+            assert np.abs(A @ X[i] - B[i]).max() <= 1e-10 * np.abs(B[i]).max()
+
+
 @pytest.mark.gpu
 def test_factor_export_import_roundtrip_on_the_gpu(gpu):
     """What solve_many_rhs broadcasts: a second handle with the same analysis solves from imported panels."""

@@ -509,6 +509,38 @@ def test_config5_at_its_own_size_one_gpu(gpu, orc):
         assert_factor_equal(n, (Lp, Li, Lx), _oracle_chol(orc, n, Ap, Ai, AX[i], q), "config-5 matrix %d" % i)
 
 
+def test_fused_permutation_graphs_survive_rotating_buffers(gpu):
+    """From 256 right-hand sides on the sweeps address the caller's array directly, so solve graphs are cached per
+    (count, address), eight at a time: twelve different buffers, visited twice, must all come back solved (the ninth
+    empties the cache; a stale graph would write into another buffer)."""
+    import torch
+    m, n, Ap, Ai, Ax = synth.grid_jacobian(n=2500, seed=12)
+    A = csc_to_scipy(m, n, Ap, Ai, Ax)
+    k = 256
+    dev = torch.device("cuda", 0)
+    sh = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(5)
+    Bs = [rng.standard_normal((n, k)) for _ in range(12)]
+    with gpu.Factorization(m, n, Ap, Ai) as F:
+        F.factor(Ax, 1e-3)
+        bufs = [torch.from_numpy(b).to(dev) for b in Bs]
+        first = []
+        for x in bufs:
+            F.solve_dev(x.data_ptr(), k, sh)
+        torch.cuda.synchronize()
+        first = [x.cpu().numpy() for x in bufs]
+        for x, b in zip(bufs, Bs):                                       # second visit: fresh right-hand sides, same addresses
+            x.copy_(torch.from_numpy(b))
+        for x in reversed(bufs):
+            F.solve_dev(x.data_ptr(), k, sh)
+        torch.cuda.synchronize()
+        second = [x.cpu().numpy() for x in bufs]
+    scale = abs(A).sum(axis=0).max()
+    for X, X2, b in zip(first, second, Bs):
+        assert np.abs(A @ X - b).max() <= 1e-13 * (scale * np.abs(X).max() + np.abs(b).max())
+        assert np.array_equal(X, X2)
+
+
 # ------------------------------------------------------------- edge cases ----
 
 def _arrow_with_dense_row(n=400, seed=0):

@@ -3499,7 +3499,9 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
     } else if (g.cls == SK_SMALL && nrhs >= RHS_LANES_MIN) {
         // the fronts of order <= 16 come first in the group: half the registers per wave, twice the waves per CU
         // (these sweeps are bound by memory latency times occupancy); the two launches are independent
-        static const bool split16 = !(getenv("CS3_NO_SPLIT16") && getenv("CS3_NO_SPLIT16")[0] == '1');
+        // (off since the slot-round assembly freed the LDS: 256 right-hand sides 1.01 ms split, 0.945 not; 1024: 1.637 / 1.627;
+        //  CS3_SPLIT16=1 turns it on)
+        static const bool split16 = getenv("CS3_SPLIT16") && getenv("CS3_SPLIT16")[0] == '1';
         const int n16 = (split16 && nrhs >= 256 && g.max_r > 16) ? g.n16 : 0;     // (an extra launch per level: pays with many tiles)
         if (n16 > 0) launch_rhs_sweep<KIND, 16>(D, g.first, n16, X, nrhs, forward, st);
         const int f2 = g.first + n16, c2 = g.count - n16;
@@ -3573,8 +3575,10 @@ hipError_t launch_solve_levels(const DeviceFactor &D, const std::vector<LaunchGr
     // one right-hand side: the per-level launches are short, fork/join costs more than it hides (measured), so they stay
     // in line.  Many right-hand sides: the lane = right-hand-side group and the GEMM group of a level take 10-40 us each
     // and are independent -- side by side they save 60 us of 1.73 ms at 1024 right-hand sides, 24 us of 0.83 at 128.
+    // (re-measured with the fronts of order 33-64 on the GEMM sweeps: the fork now pays from 512 right-hand sides on only
+    //  -- 128: 0.82 ms forked, 0.77 in line; 256: equal; 1024: equal to 0.5 %)
     static const char *sf = getenv("CS3_SOLVE_FORK");
-    const bool solve_parallel = sf ? sf[0] == '1' : nrhs >= RHS_LANES_MIN;
+    const bool solve_parallel = sf ? sf[0] == '1' : nrhs >= 512;
     auto launch = [&](const LaunchGroup &g, hipStream_t s) {
         return (D.kind == CS3_LU) ? launch_solve_group<CS3_LU>(D, g, X, nrhs, forward, s)
                                   : launch_solve_group<CS3_CHOLESKY>(D, g, X, nrhs, forward, s);

@@ -14,7 +14,8 @@ hot-path GPU check went through oracle/liboracle.so.  These fixtures are compute
     numpy.linalg.solve (LAPACK, partial pivoting) and scipy.sparse.linalg.splu (SuperLU) before it is saved.
 
 Inputs are the seeded generators of csparse3_amd/synth.py: toy10 (config 1) and jacobian_config2 (config 2 at
-its stated ~400 x 400 / ~3k nnz), plus the 118-bus-sized jacobian_like.
+its stated ~400 x 400 / ~3k nnz), the 118-bus-sized jacobian_like, a 1500-column grid Jacobian (fronts up to the
+LDS-resident block kernels) and a 500-column matrix with a dense 180-column block (the blocked big-front path).
 
     python tests/golden/make_factor_fixtures.py
 """
@@ -126,6 +127,10 @@ def main():
     out["toy10_b_known"], out["toy10_x_known"] = b, xt                # b = A (1..10): the answer is 1..10
     case("jac118", *synth.jacobian_like(), rng, out)
     case("config2", *synth.jacobian_config2(), rng, out)
+    # beyond the one-wave kernels: fronts of order 33-136 (grid1500) and a dense 180-pivot root on the blocked
+    # big-front path (block500) -- the same extended-precision elimination, a few seconds each
+    case("grid1500", *synth.grid_jacobian(n=1500, seed=15), rng, out)
+    case("block500", *synth.dense_block_matrix(n=500, nd=180, seed=3), rng, out)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
 

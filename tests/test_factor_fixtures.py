@@ -1,4 +1,4 @@
-"""Oracle-INDEPENDENT known answers for BASELINE configs 1 and 2 (tests/golden/factor_fixtures.npz).
+"""Oracle-INDEPENDENT known answers for BASELINE configs 1 and 2 and two larger cases (tests/golden/factor_fixtures.npz).
 
 The fixtures hold A, b, the pivot order and dense L, U, Cholesky L and x computed in extended precision by
 tests/golden/make_factor_fixtures.py (cross-checked there against LAPACK and SuperLU).  Nothing here goes
@@ -16,7 +16,7 @@ import pytest
 from helpers import RTOL
 
 FIX = np.load(os.path.join(os.path.dirname(__file__), "golden", "factor_fixtures.npz"))
-TAGS = ["toy10", "jac118", "config2"]
+TAGS = ["toy10", "jac118", "config2", "grid1500", "block500"]    # the last two: fronts beyond the one-wave kernels, a dense 180-pivot root
 
 
 def _get(tag):

@@ -2106,6 +2106,7 @@ constexpr int IL_KB = 4;
 constexpr int IL_T = 8;        // rows per strip / tile
 constexpr int IL_TJ = 4;       // columns per tile of the trailing update
 constexpr int IL_NONE = INT32_MIN;             // pair source: no source (cs3::IL_ZERO)
+constexpr int IL_AV = 32;                      // assembly: sources in flight per round trip
 
 template <int KIND>
 __global__ void __launch_bounds__(64)
@@ -2135,11 +2136,11 @@ k_front_il(const FrontDesc *__restrict__ fdesc, int first, const int *__restrict
             const int have = min(64, np - base);
             const int e = base + (lane < have ? lane : 0);
             const int ptg = pr[2 * e], psr = pr[2 * e + 1];                   // pair `lane` of this block of 64
-            for (int c = 0; c < have; c += 16) {
-                double val[16];
+            for (int c = 0; c < have; c += IL_AV) {              // `have` is a multiple of 16: the tail of a block reads pair 0
+                double val[IL_AV];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int sr = bcast_lane_i(psr, c + u);                  // wave-uniform
+                for (int u = 0; u < IL_AV; ++u) {
+                    const int sr = bcast_lane_i(psr, (c + u) & 63);           // wave-uniform
                     const bool none = sr == IL_NONE;
                     const int sc = none ? 0 : sr;
                     const double *p = (sc >= 0) ? ((sc < il.len) ? (const double *) (G + (long long) sc * 64) : P + sc) : ax + ~sc;
@@ -2147,7 +2148,8 @@ k_front_il(const FrontDesc *__restrict__ fdesc, int first, const int *__restrict
                     val[u] = none ? 0.0 : v;
                 }
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
+                for (int u = 0; u < IL_AV; ++u) {
+                    if (c + u >= have) break;                                 // wave-uniform
                     const int tg = bcast_lane_i(ptg, c + u);
                     if (tg != cur) {                                          // wave-uniform
                         if (cur >= 0) F[(long long) cur * 64] = acc;

@@ -1,13 +1,7 @@
 set -e
-run() { tag=$1; shift; env "$@" python bench.py --configs=5 --no-cpu-baseline --steps 20 > gpurun_out/rx_$tag.log 2>&1; }
-run base CS3_DUMMY=1
-run m32 CS3_MIX_RMAX=32
-run m48 CS3_MIX_RMAX=48
-run base2 CS3_DUMMY=1
-run m32b CS3_MIX_RMAX=32
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_factor_fixtures.py -x -q -m gpu -k "interleaved or batch or own_size or config5" > gpurun_out/t5.log 2>&1; tail -2 gpurun_out/t5.log
+for i in 1 2 3; do python bench.py --configs=5 --no-cpu-baseline --steps 20 > gpurun_out/rx_a$i.log 2>&1; done
 python - <<PY
 import json
-for f in ("base","m32","m48","base2","m32b"):
-    d=json.loads(open("gpurun_out/rx_%s.log"%f).read().strip().splitlines()[-1])["configs"]["5"]
-    print(f, round(d["factor_solve_ms"],3), "res", d["rel_residual"])
+print([round(json.loads(open("gpurun_out/rx_a%d.log"%i).read().strip().splitlines()[-1])["configs"]["5"]["factor_solve_ms"],3) for i in (1,2,3)])
 PY

@@ -108,6 +108,7 @@ def lib():
         for f in (L.cs3_solve_dev, L.cs3_lsolve_dev, L.cs3_usolve_dev):
             f.argtypes = [vp, vp, I64, vp]
         L.cs3_residual_dev.argtypes = [vp, vp, vp, vp, vp, I64, vp]
+        L.cs3_matvec_dev.argtypes = [vp, vp, vp, vp, I64, vp]
         L.cs3_refine_dev.argtypes = [vp, vp, vp, vp, I64, I64, C.POINTER(C.c_double), vp]
         L.cs3_export_factor_dev.argtypes = [vp, vp, vp]
         L.cs3_import_factor_dev.argtypes = [vp, vp, vp]
@@ -314,6 +315,10 @@ class Factorization:
         """R = B - A X on resident data (A's values at ax_ptr, the analysed pattern); csc_mat_vec_ff's summation order."""
         _check(lib().cs3_residual_dev(self._h, C.c_void_p(ax_ptr), C.c_void_p(b_ptr), C.c_void_p(x_ptr), C.c_void_p(r_ptr), k,
                                       C.c_void_p(stream)))
+
+    def matvec_dev(self, ax_ptr, x_ptr, y_ptr, k=1, stream=0):
+        """Y = A X on resident data (the analysed pattern, values at ax_ptr), summed as csc_mat_vec_ff sums."""
+        _check(lib().cs3_matvec_dev(self._h, C.c_void_p(ax_ptr), C.c_void_p(x_ptr), C.c_void_p(y_ptr), k, C.c_void_p(stream)))
 
     def refine_dev(self, ax_ptr, b_ptr, x_ptr, k=1, steps=1, stream=0, want_correction=True):
         """`steps` rounds of x += A \\ (b - A x) with the factors at hand; returns max |dx| of the last round."""

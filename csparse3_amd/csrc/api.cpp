@@ -904,6 +904,16 @@ int cs3_residual_dev(cs3_handle h, const double *Ax_dev, const double *B_dev, co
     return CS3_OK;
 }
 
+// Y = A X on resident data, the products of a row summed in csc_mat_vec_ff's order (bit-exact with cs3_csc_matvec)
+int cs3_matvec_dev(cs3_handle h, const double *Ax_dev, const double *X_dev, double *Y_dev, int64_t k, void *stream)
+{
+    int rc = guard(h); if (rc) return rc;
+    if (!Ax_dev || !X_dev || !Y_dev || k < 1 || k > INT_MAX) { set_error("cs3_matvec_dev: bad argument"); return CS3_ERR_ARG; }
+    if ((rc = ensure_row_view(h, 0))) return rc;
+    CS3_HIP(launch_residual(h->d_rp, h->d_rj, h->d_rmap, Ax_dev, X_dev, nullptr, Y_dev, h->S.n, (int) k, h->S.nnzA, h->batch, (hipStream_t) stream));
+    return CS3_OK;
+}
+
 int cs3_refine_dev(cs3_handle h, const double *Ax_dev, const double *B_dev, double *X_dev, int64_t k, int64_t steps,
                    double *last_correction, void *stream)
 {

@@ -2944,7 +2944,7 @@ k_residual_rows(const int *__restrict__ Rp, const int *__restrict__ Rj, const in
 {
     const double *Ax = Ax_all + (long long) blockIdx.y * nnz_a;
     const double *X = X_all + (long long) blockIdx.y * n * nrhs;
-    const double *B = B_all + (long long) blockIdx.y * n * nrhs;
+    const double *B = B_all ? B_all + (long long) blockIdx.y * n * nrhs : nullptr;      // null: R = A X (the SpMV alone)
     double *R = R_all + (long long) blockIdx.y * n * nrhs;
     const long long total = n * nrhs;
     for (long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long) gridDim.x * blockDim.x) {
@@ -2956,7 +2956,7 @@ k_residual_rows(const int *__restrict__ Rp, const int *__restrict__ Rj, const in
             const double prod = Ax[Rmap[p]] * X[(long long) Rj[p] * nrhs + t];
             y = y + prod;
         }
-        R[e] = B[e] - y;
+        R[e] = B ? B[e] - y : y;
     }
 }
 

@@ -136,6 +136,8 @@ int cs3_usolve_dev(cs3_handle h, double *X_dev, int64_t k, void *stream);
  * the add), so results are reproducible and A X equals the reference's matvec bit for bit. */
 int cs3_residual_dev(cs3_handle h, const double *Ax_dev, const double *B_dev, const double *X_dev, double *R_dev,
                      int64_t k, void *stream);
+/* Y = A X alone, same summation (the device-resident csc_mat_vec_ff; cs3_csc_matvec is the host-pointer form). */
+int cs3_matvec_dev(cs3_handle h, const double *Ax_dev, const double *X_dev, double *Y_dev, int64_t k, void *stream);
 /* `steps` rounds of  x += A \ (b - A x)  with the factors the handle holds (e.g. factors of an earlier Newton iterate
  * refining the solution for the current values Ax_dev).  last_correction (optional): max |dx| of the last round
  * (reading it synchronises the stream). */

@@ -832,6 +832,24 @@ def test_fused_root_pipeline_block_and_chunk_combinations(gpu, nd, nrhs, chol):
 
 # ----------------------------------------------- residual and iterative refinement ----
 
+def test_matvec_on_resident_data_is_bit_exact_with_the_host_entry_point(gpu):
+    """cs3_matvec_dev (the handle's pattern, resident values and vectors) against cs3_csc_matvec: the same sums, bit for bit."""
+    import torch
+    m, n, Ap, Ai, Ax = synth.grid_jacobian(n=4000, seed=21)
+    rng = np.random.default_rng(2)
+    X = rng.standard_normal((n, 3))
+    dev = torch.device("cuda", 0)
+    sh = torch.cuda.current_stream().cuda_stream
+    with gpu.Factorization(m, n, Ap, Ai) as F:
+        d_ax, d_x = torch.from_numpy(Ax.copy()).to(dev), torch.from_numpy(X).to(dev)
+        d_y = torch.empty_like(d_x)
+        F.matvec_dev(d_ax.data_ptr(), d_x.data_ptr(), d_y.data_ptr(), 3, sh)
+        torch.cuda.synchronize()
+        Y = d_y.cpu().numpy()
+    for t in range(3):
+        assert np.array_equal(Y[:, t], gpu.csc_mat_vec_ff(m, n, Ap, Ai, Ax, np.ascontiguousarray(X[:, t])))
+
+
 def test_residual_and_refinement_on_resident_data(gpu):
     """cs3_residual_dev reproduces b - csc_mat_vec_ff(A, x) bit for bit (golden matvec outputs of the reference);
     cs3_refine_dev with the factors of a NEARBY matrix (a stale Newton iterate) drives the residual of the current

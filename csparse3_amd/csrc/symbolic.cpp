@@ -319,10 +319,14 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     //          whose columns end where its own begin) when that adds few explicit
     //          zeros.  Every dependent launch costs microseconds on the device,
     //          so a shallower tree is worth far more than the padded flops.
-    //          A batch of 64 or more matrices fills the chip at every level and runs its fronts of order <= 16 lane =
+    //          A large batch of matrices fills the chip at every level and runs its fronts of order <= 16 lane =
     //          matrix, ten times cheaper per front than the lane = row kernels above them: there a merge must earn more
     //          (measured on 512 x 5000^2: 3.83 -> 3.62 ms; 128 x 20000^2: 10.4 -> 7.5 ms; 512 x 3000^2: 2.02 -> 1.83 ms).
-    const bool batch_economy = S.batch >= 64;
+    //          (From 256 matrices on: 64 matrices -- one lane = matrix group, the per-GPU share of config 5 on eight GPUs --
+    //          are still latency-bound and prefer the shallow tree: 1.31 ms with this economy, 1.21 without; 96: 1.48 / 1.36;
+    //          128 and 192: equal; 512: 3.60 / 3.85.)
+    static const i64 economy_min = std::getenv("CS3_BATCH_ECONOMY_MIN") ? std::atoll(std::getenv("CS3_BATCH_ECONOMY_MIN")) : 256;
+    const bool batch_economy = S.batch >= economy_min;
     // (single matrices: 0.7 since round 2 -- re-measured with this round's kernels: 50k 0.871 -> 0.829 ms, 10k 0.57 -> 0.48,
     //  20k 0.75 -> 0.71, 100k equal, 200k 2.76 -> 2.62; the 0.5 of round 1 had been set with slower block-front kernels)
     double relax_z = batch_economy ? 0.25 : 0.7; i64 relax_w = batch_economy ? 4 : 8;

@@ -1,14 +1,13 @@
 set -e
-run() { tag=$1; shift; env "$@" python bench.py --configs=5 --no-cpu-baseline --steps 20 > gpurun_out/rx_$tag.log 2>&1; }
-run base CS3_DUMMY=1
-run z05 CS3_RELAX_IL_Z=0.5
-run z1 CS3_RELAX_IL_Z=1.0
-run z2 CS3_RELAX_IL_Z=2.0
-run z4 CS3_RELAX_IL_Z=4.0
-run z1r12 CS3_RELAX_IL_Z=1.0 CS3_RELAX_IL_R=12
+timeout -k 10 600 python -m pytest tests -x -q -m gpu > gpurun_out/t5.log 2>&1; tail -2 gpurun_out/t5.log
+run() { tag=$1; mats=$2; shift 2; env "$@" python bench.py --configs=5 --no-cpu-baseline --steps 20 --c5-mats $mats > gpurun_out/rx_$tag.log 2>&1; }
+for mats in 64 96 128 192 512; do
+run a_$mats $mats CS3_DUMMY=1
+run b_$mats $mats CS3_BATCH_ECONOMY_MIN=64
+run c_$mats $mats CS3_BATCH_ECONOMY_MIN=100000
+done
 python - <<PY
 import json
-for f in ("base","z05","z1","z2","z4","z1r12"):
-    d=json.loads(open("gpurun_out/rx_%s.log"%f).read().strip().splitlines()[-1])["configs"]["5"]
-    print(f, round(d["factor_solve_ms"],3), "levels", d["levels"], "res", d["rel_residual"])
+for mats in (64,96,128,192,512):
+    print(mats, [round(json.loads(open("gpurun_out/rx_%s_%d.log"%(f,mats)).read().strip().splitlines()[-1])["configs"]["5"]["factor_solve_ms"],3) for f in "abc"])
 PY

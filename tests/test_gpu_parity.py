@@ -233,7 +233,7 @@ def test_batch_of_matrices_sharing_a_pattern(gpu, orc):
 @pytest.mark.parametrize("chol", [False, True])
 @pytest.mark.parametrize("nd", [150, 260])
 def test_batched_big_fronts_in_one_workgroup(gpu, orc, chol, nd):
-    """A batch of 16 or more matrices sends fronts beyond the LDS to k_front_wg (one workgroup per front and
+    """A batch of 48 or more matrices sends fronts beyond the LDS to k_front_wg (one workgroup per front and
     matrix, one launch) and their sweeps to the single-launch block kernels: every matrix must match the oracle
     and the same matrix factorised alone (multi-launch path)."""
     import scipy.sparse as sp
@@ -244,7 +244,7 @@ def test_batched_big_fronts_in_one_workgroup(gpu, orc, chol, nd):
         S = (A + A.T).tocsc(); S.sort_indices()
         Ap, Ai, Ax = S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.copy()
         kind = gpu.CS3_CHOLESKY
-    nb = 18
+    nb = 50
     rng = np.random.default_rng(nd)
     AX = Ax[None, :] * (1.0 + 0.03 * rng.uniform(-1.0, 1.0, size=(nb, len(Ax))))
     if chol:                                           # keep the perturbed matrices symmetric: scale whole matrices instead

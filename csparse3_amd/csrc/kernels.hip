@@ -79,6 +79,7 @@ __device__ __forceinline__ double *il_lane_base(const IlView &il, long long m)
 constexpr int ASM_DUMMY_T = 0x3fffffff;
 constexpr int ASM_LONG_T = 0x40000000;
 constexpr int GATHER_UNROLL = 4;
+constexpr int GATHER_UNROLL_BIG = 16;           // k_front_wg: 130 entries per thread on a 257 x 257 root, two round trips per pass
 constexpr int GATHER_UNROLL_WG = 8;             // one workgroup of 8 waves per front (fronts of order > 64): 4096 entries per pass
 
 // Fetch(s) returns the address of source s (an unconditional load keeps loads in flight).
@@ -797,7 +798,7 @@ k_front_wg(const FrontDesc *__restrict__ fdesc, int first,
     for (long long e = tid; e < (long long) r * r; e += 512) F[e] = 0.0;
     __syncthreads();
     CS3_WSTAMP(0);
-    gather_front<GATHER_UNROLL_WG>(d.asm_begin, d.asm_count >> 6, wv, 8, asm_src, asm_tgt, long_src,
+    gather_front<GATHER_UNROLL_BIG>(d.asm_begin, d.asm_count >> 6, wv, 8, asm_src, asm_tgt, long_src,
                  [&](int q) -> const double * { return (q >= 0) ? ((q < il.len) ? pil + (long long) q * 64 : pool + q) : ax + ~q; },
                  [&](int t, double v) { pool[t] = v; });
     __syncthreads();

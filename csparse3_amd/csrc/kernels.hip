@@ -1612,16 +1612,41 @@ k_bwd_blk(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ s
     __syncthreads();
     const double *L = pool + d.lpan;
     const double *U = pool + d.upan;
-    // v1 -= U12 v2: one wave per pivot row, lanes across the ancestors, fixed-order reduction
-    for (int i = wv; i < w; i += 4) {
-        double acc = 0.0;
-        for (int j = lane; j < nb; j += 64) {
-            const double u = (KIND == CS3_LU) ? U[(long long) i * d.u_sk + (long long) j * d.u_sj]
-                                              : L[(long long) (w + j) + (long long) i * r];
-            acc += u * v[w + j];
+    // v1 -= U12 v2: one wave per pivot row, lanes across the ancestors, fixed-order reduction.  A wave takes RB of its
+    // rows and JU strides of 64 ancestors per pass and issues those RB x JU loads together (one round trip instead of
+    // one per row); every row still sums its products in ascending order of the ancestors, as before.
+    {
+        constexpr int RB = 8, JU = 4;
+        for (int i0 = wv; i0 < w; i0 += 4 * RB) {
+            double acc[RB];
+#pragma unroll
+            for (int q = 0; q < RB; ++q) acc[q] = 0.0;
+            for (int j0 = 0; j0 < nb; j0 += 64 * JU) {
+                double u[RB][JU];
+#pragma unroll
+                for (int q = 0; q < RB; ++q)
+#pragma unroll
+                    for (int t = 0; t < JU; ++t) {
+                        const int i = i0 + 4 * q, j = j0 + 64 * t + lane;
+                        const long long off = (KIND == CS3_LU) ? (long long) i * d.u_sk + (long long) j * d.u_sj
+                                                               : (long long) (w + j) + (long long) i * r;
+                        u[q][t] = load_if((KIND == CS3_LU) ? U : L, off, i < w && j < nb);
+                    }
+#pragma unroll
+                for (int t = 0; t < JU; ++t) {
+                    const int j = j0 + 64 * t + lane;
+                    const double vj = (j < nb) ? v[w + j] : 0.0;
+#pragma unroll
+                    for (int q = 0; q < RB; ++q) acc[q] += u[q][t] * vj;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < RB; ++q) {
+                double a = acc[q];
+                for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+                if (lane == 0 && i0 + 4 * q < w) v[i0 + 4 * q] -= a;
+            }
         }
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-        if (lane == 0) v[i] -= acc;
     }
     __syncthreads();
     // back substitution, chunks of 64 columns from the right

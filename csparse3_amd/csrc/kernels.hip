@@ -402,10 +402,16 @@ front_wave_body(const FrontDesc &d, int first, double *F,
 #pragma unroll
                 for (int j0 = (k + 2) & ~7; j0 < NC; j0 += 8) {
                     if (j0 < r) {                               // skip register groups beyond the front
+                        // the group's broadcasts first, then its FMAs: a lane-to-scalar read needs wait states before
+                        // the vector instruction that consumes it, which the next broadcasts fill
+                        double bc[8];
+#pragma unroll
+                        for (int j = (j0 > k + 2 ? j0 : k + 2); j < j0 + 8; ++j)
+                            bc[j - j0] = (KIND == CS3_LU) ? bcast_lane(row[j], k) : bcast_lane(row[k], j);
 #pragma unroll
                         for (int j = (j0 > k + 2 ? j0 : k + 2); j < j0 + 8; ++j) {
-                            if (KIND == CS3_LU) row[j] -= l * bcast_lane(row[j], k);
-                            else { const double lj = bcast_lane(row[k], j); row[j] -= (lane >= j ? l : 0.0) * lj; }
+                            if (KIND == CS3_LU) row[j] -= l * bc[j - j0];
+                            else row[j] -= (lane >= j ? l : 0.0) * bc[j - j0];
                         }
                     }
                 }
@@ -556,6 +562,7 @@ k_big_gather(const FrontDesc *__restrict__ fdesc, int first,
 template <int KIND, int NBK>
 __device__ __forceinline__ void eliminate_block(double (&d)[NBK], bool keep_unscaled)
 {
+    constexpr int EB = 8;                       // columns whose broadcasts are issued together
     const int lane = threadIdx.x & 63;
     const bool stacked = lane >= 32;
     double piv = bcast_lane(d[0], 0);
@@ -574,10 +581,24 @@ __device__ __forceinline__ void eliminate_block(double (&d)[NBK], bool keep_unsc
             dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
             rp = fast_rcp(dg);
         }
+        // the broadcasts of EB columns go out before their FMAs: a lane-to-scalar read needs wait states before the
+        // vector instruction that consumes it, which the next broadcasts fill
 #pragma unroll
-        for (int j = k + 2; j < NBK; ++j) {
-            if (KIND == CS3_LU) d[j] -= l * bcast_lane(d[j], k);
-            else { const double lj = bcast_lane(d[k], j); if (lane >= j) d[j] -= l * lj; }      // L(j, k): lane j, register k
+        for (int j0 = k + 2; j0 < NBK; j0 += EB) {
+            double bc[EB];
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
+                const int j = j0 + u;
+                if (j < NBK) bc[u] = (KIND == CS3_LU) ? bcast_lane(d[j], k) : bcast_lane(d[k], j);
+            }
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
+                const int j = j0 + u;
+                if (j < NBK) {
+                    if (KIND == CS3_LU) d[j] -= l * bc[u];
+                    else if (lane >= j) d[j] -= l * bc[u];                          // L(j, k): lane j, register k
+                }
+            }
         }
     }
 }

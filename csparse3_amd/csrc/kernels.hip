@@ -1455,9 +1455,12 @@ k_fwd_rhs(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ s
             if (KIND == CS3_CHOLESKY) v[k] *= bcast_lane(rd, k);
 #pragma unroll
             for (int i0 = (k + 1) & ~7; i0 < RMAX; i0 += 8) {
-                if (i0 < r) {
+                if (i0 < r) {                                   // the group's panel entries first, then its FMAs (see eliminate_block)
+                    double pe[8];
 #pragma unroll
-                    for (int i = (i0 > k + 1 ? i0 : k + 1); i < i0 + 8; ++i) v[i] -= P.at(i, k) * v[k];
+                    for (int i = (i0 > k + 1 ? i0 : k + 1); i < i0 + 8; ++i) pe[i - i0] = P.at(i, k);
+#pragma unroll
+                    for (int i = (i0 > k + 1 ? i0 : k + 1); i < i0 + 8; ++i) v[i] -= pe[i - i0] * v[k];
                 }
             }
         }
@@ -1521,10 +1524,14 @@ k_bwd_rhs(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ s
             if (t < w) x[t] *= bcast_lane(rd, t);
 #pragma unroll
             for (int i0 = 0; i0 < t; i0 += 8) {
-                if (i0 < w) {
+                if (i0 < w) {                                   // the group's panel entries first, then its FMAs
+                    double pe[8];
 #pragma unroll
                     for (int i = i0; i < i0 + 8; ++i)
-                        if (i < t) x[i] -= M.at(i, t) * x[t];
+                        if (i < t) pe[i - i0] = M.at(i, t);
+#pragma unroll
+                    for (int i = i0; i < i0 + 8; ++i)
+                        if (i < t) x[i] -= pe[i - i0] * x[t];
                 }
             }
         }

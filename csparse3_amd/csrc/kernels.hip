@@ -1751,65 +1751,59 @@ k_fwd_big_gather(const SolveDesc *__restrict__ sd, int first,
 // are in flight while the first is being solved.
 template <int KIND, bool FORWARD>
 struct BlockTriangle {
+    // Row `lane` of the 64 x 64 triangle, STRICTLY off the diagonal and already divided by the row's own diagonal entry
+    // (backward sweep, Cholesky forward sweep), zero outside bw x bw: a substitution step is then one lane-to-scalar
+    // broadcast and one FMA -- no per-step scaling, no predicate, no branch on the block's width (round 2: the chain of
+    // 64 steps took 136-192 cycles per step in the root's sweeps).
     double t[SOLVE_BW];
-    double rdg;
+    double rdg;                                 // 1 / diagonal entry of my row (1 where nothing is divided)
     __device__ __forceinline__ void load(const double *__restrict__ L, long long r, int kb, int bw)
     {
         const int lane = threadIdx.x & 63;
         const int i = kb + lane;
+        rdg = (!FORWARD || KIND == CS3_CHOLESKY) ? recip_diag(L, i, r, lane < bw) : 1.0;
 #pragma unroll
         for (int j = 0; j < SOLVE_BW; ++j) {
             long long off;
             bool need;
-            if (FORWARD) { off = (long long) i + (long long) (kb + j) * r; need = lane >= j; }
+            if (FORWARD) { off = (long long) i + (long long) (kb + j) * r; need = lane > j; }
             else {
                 off = (KIND == CS3_LU) ? (long long) i + (long long) (kb + j) * r : (long long) (kb + j) + (long long) i * r;
-                need = lane <= j;
+                need = lane < j;
             }
             t[j] = load_if(L, off, j < bw && lane < bw && need);
         }
-        rdg = (!FORWARD || KIND == CS3_CHOLESKY) ? recip_diag(L, i, r, lane < bw) : 1.0;
+        if (!FORWARD || KIND == CS3_CHOLESKY) {
+#pragma unroll
+            for (int j = 0; j < SOLVE_BW; ++j) t[j] *= rdg;
+        }
     }
-    // the same for KT right-hand sides at once: one pass over the triangle, KT broadcasts per step
+    // KT right-hand sides at once: one pass over the triangle, KT broadcasts per step.  Lanes >= bw of vi must hold
+    // zeros (every caller masks its loads).
     template <int KT>
-    __device__ __forceinline__ void solve_multi(double (&vi)[KT], int bw) const
+    __device__ __forceinline__ void solve_multi(double (&vi)[KT], int) const
     {
-        const int lane = threadIdx.x & 63;
+        if (!FORWARD || KIND == CS3_CHOLESKY) {
+#pragma unroll
+            for (int q = 0; q < KT; ++q) vi[q] *= rdg;
+        }
 #pragma unroll
         for (int jj = 0; jj < SOLVE_BW; ++jj) {
             const int j = FORWARD ? jj : SOLVE_BW - 1 - jj;
-            if (j < bw) {
+            double xk[KT];
 #pragma unroll
-                for (int q = 0; q < KT; ++q) {
-                    if ((!FORWARD || KIND == CS3_CHOLESKY) && lane == j) vi[q] *= rdg;
-                    const double xk = bcast_lane(vi[q], j);
-                    if (FORWARD ? lane > j : lane < j) vi[q] -= t[j] * xk;
-                }
-            }
+            for (int q = 0; q < KT; ++q) xk[q] = bcast_lane(vi[q], j);
+#pragma unroll
+            for (int q = 0; q < KT; ++q) vi[q] -= t[j] * xk[q];
         }
     }
-    __device__ __forceinline__ double solve(double vi, int bw) const
+    __device__ __forceinline__ double solve(double vi, int) const
     {
-        const int lane = threadIdx.x & 63;
-        if (FORWARD) {
+        if (!FORWARD || KIND == CS3_CHOLESKY) vi *= rdg;
 #pragma unroll
-            for (int j = 0; j < SOLVE_BW; ++j) {
-                if (j < bw) {
-                    if (KIND == CS3_CHOLESKY && lane == j) vi *= rdg;
-                    const double xk = bcast_lane(vi, j);
-                    if (lane > j) vi -= t[j] * xk;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int jj = 0; jj < SOLVE_BW; ++jj) {
-                const int j = SOLVE_BW - 1 - jj;
-                if (j < bw) {
-                    if (lane == j) vi *= rdg;
-                    const double xk = bcast_lane(vi, j);
-                    if (lane < j) vi -= t[j] * xk;
-                }
-            }
+        for (int jj = 0; jj < SOLVE_BW; ++jj) {
+            const int j = FORWARD ? jj : SOLVE_BW - 1 - jj;
+            vi -= t[j] * bcast_lane(vi, j);
         }
         return vi;
     }
@@ -1833,6 +1827,7 @@ k_fwd_big_step(const SolveDesc *__restrict__ sd, int first, int kb,
 {
     constexpr int SC = CW / 4;                      // chunk columns per wave in the slice update
     __shared__ double y[BIG_CW];
+    __shared__ double cpl[64];                      // second block's right-hand side after the coupling (wave 2 -> wave 1)
     __shared__ double part[4][64];
     const SolveDesc d = sd[first + blockIdx.z];
     const int r = d.r, w = d.w;
@@ -1859,9 +1854,15 @@ k_fwd_big_step(const SolveDesc *__restrict__ sd, int first, int kb,
         const double vi = ta.solve(load_if(v, kb + lane, lane < bwa), bwa);
         if (lane < bwa) y[lane] = vi;
         __syncthreads();
-    } else if (wv == 1 && bwb > 0) {
-        BlockTriangle<KIND, true> tb;
+        __syncthreads();
+    } else if (wv == 1) {                           // second block: its triangle; the first block's solution reaches its
+        BlockTriangle<KIND, true> tb;               //   rows through wave 2, so that no wave holds two 64 x 64 operands
         tb.load(L, r, kb + SOLVE_BW, bwb);
+        __syncthreads();
+        __syncthreads();
+        const double vi = tb.solve(cpl[lane], bwb);
+        if (lane < bwb) y[SOLVE_BW + lane] = vi;
+    } else if (wv == 2) {
         double tm[SOLVE_BW];                        // L(second block row, first block columns)
 #pragma unroll
         for (int j = 0; j < SOLVE_BW; ++j)
@@ -1870,9 +1871,10 @@ k_fwd_big_step(const SolveDesc *__restrict__ sd, int first, int kb,
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < SOLVE_BW; ++j) vi -= tm[j] * y[j];
-        vi = tb.solve(vi, bwb);
-        if (lane < bwb) y[SOLVE_BW + lane] = vi;
+        cpl[lane] = vi;
+        __syncthreads();
     } else {
+        __syncthreads();
         __syncthreads();
     }
     __syncthreads();
@@ -2074,6 +2076,7 @@ k_bwd_big_step(const SolveDesc *__restrict__ sd, int first, int chunk_from_right
 {
     constexpr int SC = CW / 4;
     __shared__ double y[BIG_CW];
+    __shared__ double cpl[64];                      // second block's right-hand side after the coupling (wave 2 -> wave 1)
     __shared__ double part[4][64];
     const SolveDesc d = sd[first + blockIdx.z];
     const int r = d.r, w = d.w;
@@ -2105,9 +2108,15 @@ k_bwd_big_step(const SolveDesc *__restrict__ sd, int first, int chunk_from_right
             if (lane < bwb) y[SOLVE_BW + lane] = vi;
         }
         __syncthreads();
-    } else if (wv == 1) {
-        BlockTriangle<KIND, false> ta;
+        __syncthreads();
+    } else if (wv == 1) {                                  // left block: its triangle; the right block's solution reaches
+        BlockTriangle<KIND, false> ta;                     //   its rows through wave 2 (no wave holds two 64 x 64 operands)
         ta.load(L, r, kb, bwa);
+        __syncthreads();
+        __syncthreads();
+        const double vi = ta.solve(cpl[lane], bwa);
+        if (lane < bwa) y[lane] = vi;
+    } else if (wv == 2) {
         double tm[SOLVE_BW];                               // U(left block row, right block columns)
 #pragma unroll
         for (int j = 0; j < SOLVE_BW; ++j) {
@@ -2119,9 +2128,10 @@ k_bwd_big_step(const SolveDesc *__restrict__ sd, int first, int chunk_from_right
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < SOLVE_BW; ++j) vi -= tm[j] * ((j < bwb) ? y[SOLVE_BW + j] : 0.0);
-        vi = ta.solve(vi, bwa);
-        if (lane < bwa) y[lane] = vi;
+        cpl[lane] = vi;
+        __syncthreads();
     } else {
+        __syncthreads();
         __syncthreads();
     }
     __syncthreads();

@@ -1558,193 +1558,6 @@ k_bwd_rhs(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ s
 // in flight).
 constexpr int SOLVE_BW = 64;
 
-template <int KIND>
-__global__ void __launch_bounds__(256)
-k_fwd_blk(const SolveDesc *__restrict__ sd, int first,
-          const int *__restrict__ fsrc, const int *__restrict__ ftgt, const int *__restrict__ flong,
-          const double *__restrict__ pool_all, double *__restrict__ cv_all, double *__restrict__ X_all,
-          int nrhs, long long pool_stride, long long cv_stride, long long x_stride)
-{
-    extern __shared__ __attribute__((aligned(16))) double v[];       // [r + 1] then y[64]
-    const SolveDesc d = sd[first + blockIdx.x];
-    const int rhs = blockIdx.z;
-    const double *pool = pool_all + (long long) blockIdx.y * pool_stride;
-    double *cv = cv_all + (long long) blockIdx.y * cv_stride;
-    double *X = X_all + (long long) blockIdx.y * x_stride;
-    const int r = d.r, w = d.w;
-    const int tid = threadIdx.x, lane = tid & 63;
-    double *y = v + r + 1;
-    for (int i = tid; i < r; i += 256) v[i] = 0.0;
-    __syncthreads();
-    gather_front(d.fasm_begin, d.fasm_count >> 6, tid >> 6, 4, fsrc, ftgt, flong,
-                 [&](int q) -> const double * {
-                     return (q >= 0) ? cv + (long long) q * nrhs + rhs : X + (long long) (~q) * nrhs + rhs;
-                 },
-                 [&](int t, double val) { v[t] = val; });
-    __syncthreads();
-    const double *L = pool + d.lpan;
-    for (int kb = 0; kb < w; kb += SOLVE_BW) {
-        const int bw = min(SOLVE_BW, w - kb);
-        if (tid < 64) {                            // triangle [kb, kb + bw): lane = row kb + lane
-            const int i = kb + lane;
-            double lrow[SOLVE_BW];
-#pragma unroll
-            for (int j = 0; j < SOLVE_BW; ++j)
-                lrow[j] = load_if(L, i + (long long) (kb + j) * r, j < bw && lane < bw && lane >= j);
-            double vi = (lane < bw) ? v[i] : 0.0;
-            const double rdg = (KIND == CS3_CHOLESKY) ? recip_diag(L, i, r, lane < bw) : 1.0;
-#pragma unroll
-            for (int j = 0; j < SOLVE_BW; ++j) {
-                if (j < bw) {
-                    if (KIND == CS3_CHOLESKY && lane == j) vi *= rdg;
-                    const double xk = bcast_lane(vi, j);
-                    if (lane > j) vi -= lrow[j] * xk;
-                }
-            }
-            if (lane < bw) { v[i] = vi; y[lane] = vi; }
-        }
-        __syncthreads();
-        for (int i = kb + bw + tid; i < r; i += 256) {      // rows below the chunk
-            double acc = 0.0;
-#pragma unroll 16
-            for (int j = 0; j < SOLVE_BW; ++j)
-                acc += load_if(L, i + (long long) (kb + j) * r, j < bw) * y[j];
-            v[i] -= acc;
-        }
-        __syncthreads();
-    }
-    for (int i = tid; i < w; i += 256) X[(long long) (d.c0 + i) * nrhs + rhs] = v[i];
-    if (d.parent >= 0)
-        for (int i = w + tid; i < r; i += 256) cv[(d.cv + i - w) * nrhs + rhs] = v[i];
-}
-
-template <int KIND>
-__global__ void __launch_bounds__(256)
-k_bwd_blk(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ st_idx,
-          const double *__restrict__ pool_all, double *__restrict__ X_all,
-          int nrhs, long long pool_stride, long long x_stride)
-{
-    extern __shared__ __attribute__((aligned(16))) double v[];       // [r + 1] then y[64]
-    const SolveDesc d = sd[first + blockIdx.x];
-    const int rhs = blockIdx.z;
-    const double *pool = pool_all + (long long) blockIdx.y * pool_stride;
-    double *X = X_all + (long long) blockIdx.y * x_stride;
-    const int r = d.r, w = d.w, nb = r - w;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int *st = st_idx + d.st;
-    double *y = v + r + 1;
-    for (int i = tid; i < r; i += 256) {
-        const long long row = (i < w) ? d.c0 + i : st[i];
-        v[i] = X[row * nrhs + rhs];
-    }
-    __syncthreads();
-    const double *L = pool + d.lpan;
-    const double *U = pool + d.upan;
-    // v1 -= U12 v2: one wave per pivot row, lanes across the ancestors, fixed-order reduction.  A wave takes RB of its
-    // rows and JU strides of 64 ancestors per pass and issues those RB x JU loads together (one round trip instead of
-    // one per row); every row still sums its products in ascending order of the ancestors, as before.
-    {
-        constexpr int RB = 8, JU = 4;
-        for (int i0 = wv; i0 < w; i0 += 4 * RB) {
-            double acc[RB];
-#pragma unroll
-            for (int q = 0; q < RB; ++q) acc[q] = 0.0;
-            for (int j0 = 0; j0 < nb; j0 += 64 * JU) {
-                double u[RB][JU];
-#pragma unroll
-                for (int q = 0; q < RB; ++q)
-#pragma unroll
-                    for (int t = 0; t < JU; ++t) {
-                        const int i = i0 + 4 * q, j = j0 + 64 * t + lane;
-                        const long long off = (KIND == CS3_LU) ? (long long) i * d.u_sk + (long long) j * d.u_sj
-                                                               : (long long) (w + j) + (long long) i * r;
-                        u[q][t] = load_if((KIND == CS3_LU) ? U : L, off, i < w && j < nb);
-                    }
-#pragma unroll
-                for (int t = 0; t < JU; ++t) {
-                    const int j = j0 + 64 * t + lane;
-                    const double vj = (j < nb) ? v[w + j] : 0.0;
-#pragma unroll
-                    for (int q = 0; q < RB; ++q) acc[q] += u[q][t] * vj;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < RB; ++q) {
-                double a = acc[q];
-                for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
-                if (lane == 0 && i0 + 4 * q < w) v[i0 + 4 * q] -= a;
-            }
-        }
-    }
-    __syncthreads();
-    // back substitution, chunks of 64 columns from the right
-    const int nchunk = (w + SOLVE_BW - 1) / SOLVE_BW;
-    for (int c = nchunk - 1; c >= 0; --c) {
-        const int kb = c * SOLVE_BW, bw = min(SOLVE_BW, w - kb);
-        if (tid < 64) {                            // triangle: lane = row kb + lane, columns kb + bw - 1 .. kb
-            const int i = kb + lane;
-            double urow[SOLVE_BW];
-#pragma unroll
-            for (int j = 0; j < SOLVE_BW; ++j) {
-                const long long off = (KIND == CS3_LU) ? (long long) i + (long long) (kb + j) * r
-                                                       : (long long) (kb + j) + (long long) i * r;
-                urow[j] = load_if(L, off, j < bw && lane < bw && lane <= j);
-            }
-            double vi = (lane < bw) ? v[i] : 0.0;
-            const double rdg = recip_diag(L, i, r, lane < bw);
-#pragma unroll
-            for (int jj = 0; jj < SOLVE_BW; ++jj) {
-                const int j = SOLVE_BW - 1 - jj;
-                if (j < bw) {
-                    if (lane == j) vi *= rdg;
-                    const double xk = bcast_lane(vi, j);
-                    if (lane < j) vi -= urow[j] * xk;
-                }
-            }
-            if (lane < bw) { v[i] = vi; y[lane] = vi; }
-        }
-        __syncthreads();
-        for (int i = tid; i < kb; i += 256) {      // pivot rows above the chunk
-            double acc = 0.0;
-#pragma unroll 16
-            for (int j = 0; j < SOLVE_BW; ++j) {
-                const long long off = (KIND == CS3_LU) ? (long long) i + (long long) (kb + j) * r
-                                                       : (long long) (kb + j) + (long long) i * r;
-                acc += load_if(L, off, j < bw) * y[j];
-            }
-            v[i] -= acc;
-        }
-        __syncthreads();
-    }
-    for (int i = tid; i < w; i += 256) X[(long long) (d.c0 + i) * nrhs + rhs] = v[i];
-}
-
-// Wide big fronts (w > 64, r > 136): the single-workgroup sweep above is bound by what one CU
-// can pull from memory, so these fronts take ONE LAUNCH PER 64-COLUMN CHUNK with many
-// workgroups, as the factorisation does: the front vector lives in HBM (bigv); in chunk launch c
-// every workgroup solves the 64 x 64 triangle of the chunk on its own (wave 0, rows in registers)
-// and then applies the chunk to ITS slice of 64 rows (4 threads per row, 16 columns each,
-// partial sums combined in a fixed order).  blockIdx.y = matrix * nrhs + right-hand side.
-__global__ void __launch_bounds__(256)
-k_fwd_big_gather(const SolveDesc *__restrict__ sd, int first,
-                 const int *__restrict__ fsrc, const int *__restrict__ ftgt, const int *__restrict__ flong,
-                 const double *__restrict__ cv_all, const double *__restrict__ X_all, double *__restrict__ bigv_all,
-                 int nrhs, long long cv_stride, long long x_stride, long long bv_size)
-{
-    const SolveDesc d = sd[first + blockIdx.z];
-    const int b = blockIdx.y / nrhs, rhs = blockIdx.y % nrhs;
-    const double *cv = cv_all + (long long) b * cv_stride;
-    const double *X = X_all + (long long) b * x_stride;
-    double *v = bigv_all + ((long long) b * nrhs + rhs) * bv_size + d.bv;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    // rows without any source (none in practice: every row has X or a child) keep what the init wrote
-    gather_front(d.fasm_begin, d.fasm_count >> 6, wave, gridDim.x * 4, fsrc, ftgt, flong,
-                 [&](int q) -> const double * {
-                     return (q >= 0) ? cv + (long long) q * nrhs + rhs : X + (long long) (~q) * nrhs + rhs;
-                 },
-                 [&](int t, double val) { v[t] = val; });
-}
-
 // Triangle of a block [kb, kb + bw), bw <= 64, by one wave: lane = row kb + lane keeps its row of the
 // triangle in registers.  FORWARD: unit lower L (Cholesky: L with its diagonal), else upper U with its
 // diagonal (Cholesky: L').  Loading and solving are separate so that the loads of a second block
@@ -1808,6 +1621,169 @@ struct BlockTriangle {
         return vi;
     }
 };
+
+template <int KIND>
+__global__ void __launch_bounds__(256)
+k_fwd_blk(const SolveDesc *__restrict__ sd, int first,
+          const int *__restrict__ fsrc, const int *__restrict__ ftgt, const int *__restrict__ flong,
+          const double *__restrict__ pool_all, double *__restrict__ cv_all, double *__restrict__ X_all,
+          int nrhs, long long pool_stride, long long cv_stride, long long x_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) double v[];       // [r + 1] then y[64]
+    const SolveDesc d = sd[first + blockIdx.x];
+    const int rhs = blockIdx.z;
+    const double *pool = pool_all + (long long) blockIdx.y * pool_stride;
+    double *cv = cv_all + (long long) blockIdx.y * cv_stride;
+    double *X = X_all + (long long) blockIdx.y * x_stride;
+    const int r = d.r, w = d.w;
+    const int tid = threadIdx.x, lane = tid & 63;
+    double *y = v + r + 1;
+    const double *L = pool + d.lpan;
+    BlockTriangle<KIND, true> tri;                 // wave 0: the first triangle's loads travel with the assembly's
+    if (tid < 64) tri.load(L, r, 0, min(SOLVE_BW, w));
+    for (int i = tid; i < r; i += 256) v[i] = 0.0;
+    __syncthreads();
+    gather_front(d.fasm_begin, d.fasm_count >> 6, tid >> 6, 4, fsrc, ftgt, flong,
+                 [&](int q) -> const double * {
+                     return (q >= 0) ? cv + (long long) q * nrhs + rhs : X + (long long) (~q) * nrhs + rhs;
+                 },
+                 [&](int t, double val) { v[t] = val; });
+    __syncthreads();
+    for (int kb = 0; kb < w; kb += SOLVE_BW) {
+        const int bw = min(SOLVE_BW, w - kb);
+        if (tid < 64) {                            // triangle [kb, kb + bw): lane = row kb + lane
+            const int i = kb + lane;
+            if (kb > 0) tri.load(L, r, kb, bw);    // (the first one came in with the assembly)
+            const double vi = tri.solve((lane < bw) ? v[i] : 0.0, bw);
+            if (lane < bw) { v[i] = vi; y[lane] = vi; }
+        }
+        __syncthreads();
+        for (int i = kb + bw + tid; i < r; i += 256) {      // rows below the chunk
+            double acc = 0.0;
+#pragma unroll 16
+            for (int j = 0; j < SOLVE_BW; ++j)
+                acc += load_if(L, i + (long long) (kb + j) * r, j < bw) * y[j];
+            v[i] -= acc;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < w; i += 256) X[(long long) (d.c0 + i) * nrhs + rhs] = v[i];
+    if (d.parent >= 0)
+        for (int i = w + tid; i < r; i += 256) cv[(d.cv + i - w) * nrhs + rhs] = v[i];
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256)
+k_bwd_blk(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ st_idx,
+          const double *__restrict__ pool_all, double *__restrict__ X_all,
+          int nrhs, long long pool_stride, long long x_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) double v[];       // [r + 1] then y[64]
+    const SolveDesc d = sd[first + blockIdx.x];
+    const int rhs = blockIdx.z;
+    const double *pool = pool_all + (long long) blockIdx.y * pool_stride;
+    double *X = X_all + (long long) blockIdx.y * x_stride;
+    const int r = d.r, w = d.w, nb = r - w;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int *st = st_idx + d.st;
+    double *y = v + r + 1;
+    const double *L = pool + d.lpan;
+    const double *U = pool + d.upan;
+    const int nchunk = (w + SOLVE_BW - 1) / SOLVE_BW;
+    BlockTriangle<KIND, false> tri;                // wave 0: the rightmost triangle's loads travel with the front vector's
+    if (tid < 64) tri.load(L, r, (nchunk - 1) * SOLVE_BW, w - (nchunk - 1) * SOLVE_BW);
+    for (int i = tid; i < r; i += 256) {
+        const long long row = (i < w) ? d.c0 + i : st[i];
+        v[i] = X[row * nrhs + rhs];
+    }
+    __syncthreads();
+    // v1 -= U12 v2: one wave per pivot row, lanes across the ancestors, fixed-order reduction.  A wave takes RB of its
+    // rows and JU strides of 64 ancestors per pass and issues those RB x JU loads together (one round trip instead of
+    // one per row); every row still sums its products in ascending order of the ancestors, as before.
+    {
+        constexpr int RB = 8, JU = 4;
+        for (int i0 = wv; i0 < w; i0 += 4 * RB) {
+            double acc[RB];
+#pragma unroll
+            for (int q = 0; q < RB; ++q) acc[q] = 0.0;
+            for (int j0 = 0; j0 < nb; j0 += 64 * JU) {
+                double u[RB][JU];
+#pragma unroll
+                for (int q = 0; q < RB; ++q)
+#pragma unroll
+                    for (int t = 0; t < JU; ++t) {
+                        const int i = i0 + 4 * q, j = j0 + 64 * t + lane;
+                        const long long off = (KIND == CS3_LU) ? (long long) i * d.u_sk + (long long) j * d.u_sj
+                                                               : (long long) (w + j) + (long long) i * r;
+                        u[q][t] = load_if((KIND == CS3_LU) ? U : L, off, i < w && j < nb);
+                    }
+#pragma unroll
+                for (int t = 0; t < JU; ++t) {
+                    const int j = j0 + 64 * t + lane;
+                    const double vj = (j < nb) ? v[w + j] : 0.0;
+#pragma unroll
+                    for (int q = 0; q < RB; ++q) acc[q] += u[q][t] * vj;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < RB; ++q) {
+                double a = acc[q];
+                for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+                if (lane == 0 && i0 + 4 * q < w) v[i0 + 4 * q] -= a;
+            }
+        }
+    }
+    __syncthreads();
+    // back substitution, chunks of 64 columns from the right
+    for (int c = nchunk - 1; c >= 0; --c) {
+        const int kb = c * SOLVE_BW, bw = min(SOLVE_BW, w - kb);
+        if (tid < 64) {                            // triangle: lane = row kb + lane, columns kb + bw - 1 .. kb
+            const int i = kb + lane;
+            if (c < nchunk - 1) tri.load(L, r, kb, bw);     // (the rightmost one came in with the front vector)
+            const double vi = tri.solve((lane < bw) ? v[i] : 0.0, bw);
+            if (lane < bw) { v[i] = vi; y[lane] = vi; }
+        }
+        __syncthreads();
+        for (int i = tid; i < kb; i += 256) {      // pivot rows above the chunk
+            double acc = 0.0;
+#pragma unroll 16
+            for (int j = 0; j < SOLVE_BW; ++j) {
+                const long long off = (KIND == CS3_LU) ? (long long) i + (long long) (kb + j) * r
+                                                       : (long long) (kb + j) + (long long) i * r;
+                acc += load_if(L, off, j < bw) * y[j];
+            }
+            v[i] -= acc;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < w; i += 256) X[(long long) (d.c0 + i) * nrhs + rhs] = v[i];
+}
+
+// Wide big fronts (w > 64, r > 136): the single-workgroup sweep above is bound by what one CU
+// can pull from memory, so these fronts take ONE LAUNCH PER 64-COLUMN CHUNK with many
+// workgroups, as the factorisation does: the front vector lives in HBM (bigv); in chunk launch c
+// every workgroup solves the 64 x 64 triangle of the chunk on its own (wave 0, rows in registers)
+// and then applies the chunk to ITS slice of 64 rows (4 threads per row, 16 columns each,
+// partial sums combined in a fixed order).  blockIdx.y = matrix * nrhs + right-hand side.
+__global__ void __launch_bounds__(256)
+k_fwd_big_gather(const SolveDesc *__restrict__ sd, int first,
+                 const int *__restrict__ fsrc, const int *__restrict__ ftgt, const int *__restrict__ flong,
+                 const double *__restrict__ cv_all, const double *__restrict__ X_all, double *__restrict__ bigv_all,
+                 int nrhs, long long cv_stride, long long x_stride, long long bv_size)
+{
+    const SolveDesc d = sd[first + blockIdx.z];
+    const int b = blockIdx.y / nrhs, rhs = blockIdx.y % nrhs;
+    const double *cv = cv_all + (long long) b * cv_stride;
+    const double *X = X_all + (long long) b * x_stride;
+    double *v = bigv_all + ((long long) b * nrhs + rhs) * bv_size + d.bv;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // rows without any source (none in practice: every row has X or a child) keep what the init wrote
+    gather_front(d.fasm_begin, d.fasm_count >> 6, wave, gridDim.x * 4, fsrc, ftgt, flong,
+                 [&](int q) -> const double * {
+                     return (q >= 0) ? cv + (long long) q * nrhs + rhs : X + (long long) (~q) * nrhs + rhs;
+                 },
+                 [&](int t, double val) { v[t] = val; });
+}
 
 // One launch per chunk of BIG_CW = 128 pivot columns = two blocks of 64.  Every workgroup solves the
 // chunk on its own: wave 0 the first block, wave 1 the second after taking the first block's

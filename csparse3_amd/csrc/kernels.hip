@@ -1234,26 +1234,34 @@ k_fwd_wave(const SolveDesc *__restrict__ sd, int first, int count,
 #pragma unroll
     for (int q = 0; q < KT; ++q) { v0[q] = vs[wv][q][lane]; v1[q] = vs[wv][q][lane + 64]; }
     const double *L = pool + d.lpan;
+    // Cholesky: row i < w of the panel and of the vector is divided by L_ii up front (rdg = 1 on the other rows), so that a
+    // column step is one lane-to-scalar broadcast and the FMAs
     const double rdg = (KIND == CS3_CHOLESKY) ? recip_diag(L, lane, r, lane < w) : 1.0;
+    if (KIND == CS3_CHOLESKY) {
+#pragma unroll
+        for (int q = 0; q < KT; ++q) v0[q] *= rdg;
+    }
     for (int k0 = 0; k0 < w; k0 += SOLVE_PF) {
         double l0[SOLVE_PF], l1[SOLVE_PF];
 #pragma unroll
         for (int j = 0; j < SOLVE_PF; ++j) {
             const int k = k0 + j;
-            l0[j] = load_if(L, lane + (long long) k * r, k < w && lane < r && lane >= k);
+            l0[j] = load_if(L, lane + (long long) k * r, k < w && lane < r && lane > k);
             l1[j] = load_if(L, lane + 64 + (long long) k * r, k < w && lane + 64 < r);
         }
+        if (KIND == CS3_CHOLESKY) {
+#pragma unroll
+            for (int j = 0; j < SOLVE_PF; ++j) l0[j] *= rdg;
+        }
+        // columns past w hold zeros (masked loads): the steps run without a branch on the front's width
 #pragma unroll
         for (int j = 0; j < SOLVE_PF; ++j) {
-            const int k = k0 + j;
-            if (k < w) {
+            const int k = (k0 + j) & 63;
 #pragma unroll
-                for (int q = 0; q < KT; ++q) {
-                    if (KIND == CS3_CHOLESKY && lane == k) v0[q] *= rdg;
-                    const double xk = bcast_lane(v0[q], k);
-                    if (lane > k) v0[q] -= l0[j] * xk;
-                    v1[q] -= l1[j] * xk;
-                }
+            for (int q = 0; q < KT; ++q) {
+                const double xk = bcast_lane(v0[q], k);
+                v0[q] -= l0[j] * xk;
+                v1[q] -= l1[j] * xk;
             }
         }
     }
@@ -1295,7 +1303,11 @@ k_bwd_wave(const SolveDesc *__restrict__ sd, int first, int count, const int *__
     }
     const double *L = pool + d.lpan;
     const double *U = pool + d.upan;
+    const double rdg = recip_diag(L, lane, r, lane < w);
     // pivot row `lane` minus U(lane, k) x_k over the ancestors k = w .. r-1
+    double a0[KT], a1[KT];
+#pragma unroll
+    for (int q = 0; q < KT; ++q) a0[q] = a1[q] = 0.0;
     for (int k0 = w; k0 < r; k0 += SOLVE_PF) {
         double u[SOLVE_PF];
 #pragma unroll
@@ -1305,20 +1317,22 @@ k_bwd_wave(const SolveDesc *__restrict__ sd, int first, int count, const int *__
                                                    : (long long) k + (long long) lane * r;
             u[j] = load_if((KIND == CS3_LU) ? U : L, off, k < r && lane < w);
         }
+        // (entries past r are zeros: no branch on the front's order; the products of a row go to two sums in turn, so
+        //  that consecutive FMAs do not wait for each other)
 #pragma unroll
         for (int j = 0; j < SOLVE_PF; ++j) {
             const int k = k0 + j;
-            if (k < r) {
 #pragma unroll
-                for (int q = 0; q < KT; ++q) {
-                    const double xk = (k < 64) ? bcast_lane(v0[q], k) : bcast_lane(v1[q], k - 64);
-                    v0[q] -= u[j] * xk;
-                }
+            for (int q = 0; q < KT; ++q) {
+                const double xk = (k < 64) ? bcast_lane(v0[q], k) : bcast_lane(v1[q], (k - 64) & 63);
+                if (j & 1) a1[q] += u[j] * xk; else a0[q] += u[j] * xk;
             }
         }
     }
-    // back substitution with U11, columns w-1 .. 0
-    const double rdg = recip_diag(L, lane, r, lane < w);
+    // back substitution with U11, columns w-1 .. 0: the rows of U11 and the vector are divided by the diagonal up front, a
+    // column step is one lane-to-scalar broadcast and one FMA
+#pragma unroll
+    for (int q = 0; q < KT; ++q) v0[q] = (v0[q] - (a0[q] + a1[q])) * rdg;
     for (int k0 = w - 1; k0 >= 0; k0 -= SOLVE_PF) {
         double u[SOLVE_PF];
 #pragma unroll
@@ -1326,19 +1340,15 @@ k_bwd_wave(const SolveDesc *__restrict__ sd, int first, int count, const int *__
             const int k = k0 - j;
             const long long off = (KIND == CS3_LU) ? (long long) lane + (long long) k * r
                                                    : (long long) k + (long long) lane * r;
-            u[j] = load_if(L, off, k >= 0 && lane <= k);
+            u[j] = load_if(L, off, k >= 0 && lane < k);
         }
 #pragma unroll
-        for (int j = 0; j < SOLVE_PF; ++j) {
-            const int k = k0 - j;
-            if (k >= 0) {
+        for (int j = 0; j < SOLVE_PF; ++j) u[j] *= rdg;
 #pragma unroll
-                for (int q = 0; q < KT; ++q) {
-                    if (lane == k) v0[q] *= rdg;
-                    const double xk = bcast_lane(v0[q], k);
-                    if (lane < k) v0[q] -= u[j] * xk;
-                }
-            }
+        for (int j = 0; j < SOLVE_PF; ++j) {
+            const int k = (k0 - j) & 63;
+#pragma unroll
+            for (int q = 0; q < KT; ++q) v0[q] -= u[j] * bcast_lane(v0[q], k);
         }
     }
 #pragma unroll

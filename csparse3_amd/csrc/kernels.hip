@@ -3330,9 +3330,12 @@ static hipError_t run_level(const std::vector<LaunchGroup> &groups, size_t g0, s
     return hipSuccess;
 }
 
-hipError_t launch_factor_levels(const DeviceFactor &D, const std::vector<LaunchGroup> &groups,
+static std::vector<LaunchGroup> factor_groups(const DeviceFactor &D, const std::vector<LaunchGroup> &groups);
+
+hipError_t launch_factor_levels(const DeviceFactor &D, const std::vector<LaunchGroup> &all_groups,
                                 double inv_tol, hipStream_t st, ForkJoin &fj)
 {
+    const std::vector<LaunchGroup> groups = factor_groups(D, all_groups);
     fj.rewind();                         // (the big-front buffers were zeroed by launch_prologue)
     for (size_t g0 = 0; g0 < groups.size(); ) {
         size_t g1 = g0;
@@ -3602,27 +3605,60 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
 
 // With few right-hand sides SK_SMALL and SK_WAVE fronts share the one-wave-per-front kernels:
 // the two groups of a level are adjacent in the schedule and go out as one launch.
-static std::vector<LaunchGroup> sweep_groups(const std::vector<LaunchGroup> &groups, int nrhs)
+// A handful of small fronts beside the level's workgroup-per-front group (the top of the tree) join that group: a second
+// launch for four fronts costs a dependent launch (sweeps, 11 us) or a fork and a join across hardware queues
+// (factorisation, 13 us), the workgroup kernels take fronts of any order.  CS3_PROMOTE_MAX=0 turns it off.
+static int promote_max()
+{
+    static const int v = [] { const char *e = getenv("CS3_PROMOTE_MAX"); return e ? std::max(0, atoi(e)) : 16; }();
+    return v;
+}
+
+static void absorb_small_group(std::vector<LaunchGroup> &out, const LaunchGroup &g, int small_cls, int wg_cls)
+{
+    if (!out.empty() && out.back().level == g.level && out.back().cls == small_cls && g.cls == wg_cls &&
+        out.back().count <= promote_max() && out.back().first + out.back().count == g.first) {
+        LaunchGroup &m = out.back();
+        m.cls = wg_cls; m.count += g.count;
+        m.max_r = std::max(m.max_r, g.max_r); m.max_w = std::max(m.max_w, g.max_w); m.max_asm = std::max(m.max_asm, g.max_asm);
+        m.n16 = 0;
+    } else {
+        out.push_back(g);
+    }
+}
+
+static std::vector<LaunchGroup> sweep_groups(const std::vector<LaunchGroup> &groups, int nrhs, long long batch)
 {
     if (nrhs >= RHS_LANES_MIN) return groups;
-    std::vector<LaunchGroup> out;
+    std::vector<LaunchGroup> merged, out;
     for (const LaunchGroup &g : groups) {
-        if (!out.empty() && out.back().level == g.level && out.back().cls == SK_SMALL && g.cls == SK_WAVE &&
-            out.back().first + out.back().count == g.first) {
-            LaunchGroup &m = out.back();
+        if (!merged.empty() && merged.back().level == g.level && merged.back().cls == SK_SMALL && g.cls == SK_WAVE &&
+            merged.back().first + merged.back().count == g.first) {
+            LaunchGroup &m = merged.back();
             m.cls = SK_WAVE; m.count += g.count;
             m.max_r = std::max(m.max_r, g.max_r); m.max_w = std::max(m.max_w, g.max_w);
         } else {
-            out.push_back(g);
+            merged.push_back(g);
         }
     }
+    if (batch != 1 || promote_max() == 0) return merged;       // (a batch fills the chip with waves: one per front stays cheaper)
+    for (const LaunchGroup &g : merged) absorb_small_group(out, g, SK_WAVE, SK_BLOCK);
+    return out;
+}
+
+// the same for the factorisation of a single matrix: few fronts of order <= 64 beside the level's LDS-image fronts
+static std::vector<LaunchGroup> factor_groups(const DeviceFactor &D, const std::vector<LaunchGroup> &groups)
+{
+    if (D.batch != 1 || promote_max() == 0) return groups;
+    std::vector<LaunchGroup> out;
+    for (const LaunchGroup &g : groups) absorb_small_group(out, g, FC_R64, FC_LDS);
     return out;
 }
 
 hipError_t launch_solve_levels(const DeviceFactor &D, const std::vector<LaunchGroup> &all_groups,
                                double *X, int nrhs, bool forward, hipStream_t st, ForkJoin &fj)
 {
-    const std::vector<LaunchGroup> groups = sweep_groups(all_groups, nrhs);
+    const std::vector<LaunchGroup> groups = sweep_groups(all_groups, nrhs, D.batch);
     fj.rewind();
     // one right-hand side: the per-level launches are short, fork/join costs more than it hides (measured), so they stay
     // in line.  Many right-hand sides: the lane = right-hand-side group and the GEMM group of a level take 10-40 us each
@@ -3670,11 +3706,12 @@ static int sweep_group_cost(const LaunchGroup &g)
 // factorisation of levels K+1.. (the tail of the tree: few, large fronts, many dependent launches).
 // K is the last level whose tail is still long enough to cover the sweep; one fork, one join -- a
 // fork per level costs more than it hides (measured).  Same kernels, same operands: same bits.
-hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<LaunchGroup> &fgroups,
+hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<LaunchGroup> &all_fgroups,
                                       const std::vector<LaunchGroup> &all_sgroups, double inv_tol, double *X, int nrhs,
                                       hipStream_t st, ForkJoin &fj)
 {
-    const std::vector<LaunchGroup> sgroups = sweep_groups(all_sgroups, nrhs);
+    const std::vector<LaunchGroup> fgroups = factor_groups(D, all_fgroups);
+    const std::vector<LaunchGroup> sgroups = sweep_groups(all_sgroups, nrhs, D.batch);
     fj.rewind();
     hipError_t e;
     const int nlevels = fgroups.empty() ? 0 : fgroups.back().level + 1;

@@ -52,6 +52,7 @@ struct LaunchGroup {          // fronts of one level that share a kernel configu
     i32 max_w;                // widest supernode in the group (block steps of the big path)
     i64 max_asm;              // longest assembly list in the group
     i32 n16 = 0;              // solve groups: leading fronts of order <= 16 (sorted first: a leaner kernel instance takes them)
+    i32 need = 0;             // factor groups: lowest level that holds a parent of one of these fronts (INT32_MAX: roots only)
 };
 
 struct Symbolic {

@@ -433,6 +433,32 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         S.cb_off[s] = voff + w + w * r; S.cb_ld[s] = (i32) r;
         voff += r * r;
     }
+    // Single matrices, top of the tree: a level that holds fronts beyond the LDS runs their chain of block launches anyway;
+    // a handful of smaller fronts on the same level then ride that chain (dense r x r buffers, the same launches) instead of
+    // a launch of their own beside it -- the fork and the join across hardware queues cost the level 12-17 us, the chain
+    // takes no longer for two more tiles (round 2, profiles/r02_timeline_fused_step.json).  CS3_RIDE_MAX=0: off.
+    std::vector<i32> lvl(ns, 0);
+    for (i32 s = 0; s < ns; ++s) { const i32 p = S.sn_parent[s]; if (p >= 0) lvl[p] = std::max(lvl[p], lvl[s] + 1); }
+    std::vector<char> ride(ns, 0);
+    {
+        static const i64 ride_max = std::getenv("CS3_RIDE_MAX") ? std::atoll(std::getenv("CS3_RIDE_MAX")) : 8;
+        i32 nl = 0;
+        for (i32 s = 0; s < ns; ++s) nl = std::max(nl, lvl[s] + 1);
+        std::vector<i64> big_w(nl, 0), small_n(nl, 0), small_w(nl, 0);
+        for (i32 s = 0; s < ns && S.batch == 1; ++s) {
+            const int c = front_class(order_r(s), width(s), false, false);
+            if (c == FC_BIG) big_w[lvl[s]] = std::max(big_w[lvl[s]], width(s));
+            else { ++small_n[lvl[s]]; small_w[lvl[s]] = std::max(small_w[lvl[s]], width(s)); }
+        }
+        for (i32 s = 0; s < ns && S.batch == 1; ++s) {
+            const i32 l = lvl[s];
+            // (no more block launches than the chain has: the riders' pivots fit the blocks it runs anyway)
+            ride[s] = big_w[l] > 0 && small_n[l] <= ride_max && (small_w[l] + 31) / 32 <= (big_w[l] + 31) / 32;
+        }
+    }
+    auto class_of = [&](i32 s) -> int {
+        return ride[s] ? (int) FC_BIG : front_class(order_r(s), width(s), S.batch >= 8, interleave);
+    };
     S.sn_il_panels.assign(ns, 0);
     for (i32 s = 0; s < ns && interleave; ++s) {     // ... then the panels of the lane = row fronts that sweep lane = matrix
         const i64 w = width(s), r = order_r(s);
@@ -445,7 +471,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     S.il_len = voff;
     for (i32 s = 0; s < ns; ++s) {                   // panels of the LDS-resident fronts
         const i64 w = width(s), r = order_r(s), nb = r - w;
-        S.sn_class[s] = front_class(r, w, S.batch >= 8, interleave);
+        S.sn_class[s] = class_of(s);
         S.cv_off[s] = cvoff; cvoff += nb;
         S.rel_ptr[s + 1] = S.rel_ptr[s] + nb;
         S.max_front = std::max(S.max_front, r);
@@ -632,8 +658,17 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
             ++t;
         }
         g.count = t - g.first;
+        g.need = INT32_MAX;
+        for (i32 u = g.first; u < t; ++u) {
+            const i32 p = S.sn_parent[S.sched[u]];
+            if (p >= 0) g.need = std::min(g.need, S.sn_level[p]);
+        }
         S.groups.push_back(g);
     }
+    if (std::getenv("CS3_DEBUG_GROUPS"))
+        for (const LaunchGroup &g : S.groups)
+            std::fprintf(stderr, "factor group level %d class %d count %d max_r %d max_w %d needed at level %d\n", g.level, g.cls,
+                         g.count, g.max_r, g.max_w, g.need == INT32_MAX ? -1 : g.need);
 
     // ---- 10b. forward-solve gather lists and the solve schedule
     S.fasm_ptr.assign(ns + 1, 0);

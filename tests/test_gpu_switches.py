@@ -20,6 +20,8 @@ SETTINGS = [
     {"CS3_IL_RMAX": "24", "CS3_BLOCK_NW": "8", "CS3_BATCH_ECONOMY_MIN": "64"},
     {"CS3_WG_MIN_BATCH": "100000", "CS3_IL_MIN_BATCH": "100000"},
     {"CS3_NO_GRAPH": "1"},
+    {"CS3_PROMOTE_MAX": "0", "CS3_RIDE_MAX": "0"},
+    {"CS3_PROMOTE_MAX": "100000", "CS3_RIDE_MAX": "100000"},      # every small front beside a workgroup group joins it
 ]
 
 

@@ -17,7 +17,11 @@ src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+def newest(pattern):          # gpurun merges every call's outputs into the same directory: take the latest run's file
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+stats = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
 shutil.copy(stats, os.path.join(dst, tag + "_kernel_stats.csv"))
 
 
@@ -26,7 +30,7 @@ def short(name):
 
 
 def per_kernel(kind):
-    f = glob.glob(os.path.join(src, "pmc_" + kind, "*", "*_counter_collection.csv"))[0]
+    f = newest(os.path.join(src, "pmc_" + kind, "*", "*_counter_collection.csv"))
     tot, cnt = collections.defaultdict(float), collections.Counter()
     for r in csv.DictReader(open(f)):
         n = short(r["Kernel_Name"])

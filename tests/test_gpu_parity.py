@@ -541,6 +541,40 @@ def test_fused_permutation_graphs_survive_rotating_buffers(gpu):
         assert np.array_equal(X, X2)
 
 
+def test_fused_step_graphs_per_solution_buffer_survive_rotating_buffers(gpu):
+    """cs3_factor_solve_dev keeps a graph with the closing permutation inside for a caller that hands in the same X three
+    times in a row (four such graphs at a time): six buffers, four calls each, then interleaved calls, must all hold the
+    solution of their own right-hand side, bit-identical to the generic graph's (the first two calls)."""
+    import torch
+    m, n, Ap, Ai, Ax = synth.grid_jacobian(n=2500, seed=14)
+    A = csc_to_scipy(m, n, Ap, Ai, Ax)
+    dev = torch.device("cuda", 0)
+    sh = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(6)
+    Bs = [rng.standard_normal(n) for _ in range(6)]
+    ax = torch.from_numpy(Ax).to(dev)
+    scale = abs(A).sum(axis=0).max()
+    with gpu.Factorization(m, n, Ap, Ai) as F:
+        bufs = [torch.empty(n, dtype=torch.float64, device=dev) for _ in Bs]
+        for x, b in zip(bufs, Bs):
+            seen = []
+            for _ in range(4):
+                x.copy_(torch.from_numpy(b))
+                F.factor_solve_dev(ax.data_ptr(), x.data_ptr(), 1, 1e-3, sh)
+                torch.cuda.synchronize()
+                seen.append(x.cpu().numpy())
+            assert np.abs(A @ seen[0] - b).max() <= 1e-13 * (scale * np.abs(seen[0]).max() + np.abs(b).max())
+            for other in seen[1:]:
+                assert np.array_equal(seen[0], other)
+        for x, b in list(zip(bufs, Bs))[::-1]:                        # one call each, in another order: generic graph again
+            x.copy_(torch.from_numpy(b))
+            F.factor_solve_dev(ax.data_ptr(), x.data_ptr(), 1, 1e-3, sh)
+        torch.cuda.synchronize()
+        for x, b in zip(bufs, Bs):
+            X = x.cpu().numpy()
+            assert np.abs(A @ X - b).max() <= 1e-13 * (scale * np.abs(X).max() + np.abs(b).max())
+
+
 # ------------------------------------------------------------- edge cases ----
 
 def _arrow_with_dense_row(n=400, seed=0):

@@ -606,6 +606,92 @@ __device__ __forceinline__ void eliminate_block(double (&d)[NBK], bool keep_unsc
 template <int KIND>
 __device__ __forceinline__ void eliminate32(double (&d)[BIG_NB], bool keep_unscaled) { eliminate_block<KIND, BIG_NB>(d, keep_unscaled); }
 
+// The same elimination on a SLICE of NC columns of the stacked block: d[c] = column c0 + c, whose pivot sits in lane
+// c0 + c (lanes 0..31 are the block's rows, lanes 32..63 the stacked rows).  publish(c, l) receives the multipliers of
+// every pivot as soon as they exist, for the wave that holds the columns to the right (eliminate_pair below).
+template <int KIND, int NC, class Publish>
+__device__ __forceinline__ void eliminate_slice(double (&d)[NC], int c0, bool keep_unscaled, Publish publish)
+{
+    constexpr int EB = 8;
+    const int lane = threadIdx.x & 63;
+    const bool stacked = lane >= 32;
+    double piv = bcast_lane(d[0], c0);
+    double dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
+    double rp = fast_rcp(dg);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const int pl = c0 + k;                                  // the pivot's lane
+        const bool below = lane > pl;
+        const double l = below ? d[k] * rp : 0.0;
+        if (below && !(keep_unscaled && stacked)) d[k] = l;
+        if (KIND == CS3_CHOLESKY && lane == pl) d[k] = (piv > 0.0) ? dg : -1.0;
+        if (k + 1 < NC) {
+            if (KIND == CS3_LU) d[k + 1] -= l * bcast_lane(d[k + 1], pl);
+            else { const double lj = bcast_lane(d[k], pl + 1); if (lane >= pl + 1) d[k + 1] -= l * lj; }
+            piv = bcast_lane(d[k + 1], pl + 1);
+            dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
+            rp = fast_rcp(dg);
+        }
+        publish(k, l);
+#pragma unroll
+        for (int j0 = k + 2; j0 < NC; j0 += EB) {
+            double bc[EB];
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
+                const int j = j0 + u;
+                if (j < NC) bc[u] = (KIND == CS3_LU) ? bcast_lane(d[j], pl) : bcast_lane(d[k], c0 + j);
+            }
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
+                const int j = j0 + u;
+                if (j < NC) {
+                    if (KIND == CS3_LU) d[j] -= l * bc[u];
+                    else if (lane >= c0 + j) d[j] -= l * bc[u];
+                }
+            }
+        }
+    }
+}
+
+// A stacked 32-pivot elimination by TWO waves: a lone wave spends 425 cycles per pivot on it, nearly all of them issuing
+// two v_readlane and one FMA per column update.  Wave `part` 0 holds columns 0..15 of the 64 rows, wave 1 columns
+// 16..31.  Wave 0 eliminates its 16 pivots and hands the multipliers of each to wave 1 through LDS (lm[k][lane], then
+// *ready = k + 1: LDS operations of a wave complete in order); wave 1 applies them to its columns one pivot behind,
+// then eliminates pivots 16..31 alone.  Wave 0 never waits for wave 1, so the wait below cannot deadlock; it is bounded
+// anyway (a wave that gives up produces a wrong factor, which the residual checks catch, not a hung GPU).
+template <int KIND>
+__device__ __forceinline__ void eliminate_pair(double (&d)[BIG_NB / 2], int part, bool keep_unscaled, double *lm, volatile int *ready)
+{
+    constexpr int NC = BIG_NB / 2;
+    const int lane = threadIdx.x & 63;
+    if (part == 0) {
+        eliminate_slice<KIND, NC>(d, 0, keep_unscaled, [&](int k, double l) {
+            lm[k * 64 + lane] = l;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) *ready = k + 1;
+        });
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        for (int it = 0; *ready <= k && it < (1 << 20); ++it) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const double l = lm[k * 64 + lane];                     // zero on and above the pivot row
+#pragma unroll
+        for (int j0 = 0; j0 < NC; j0 += 8) {
+            double bc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bc[u] = (KIND == CS3_LU) ? bcast_lane(d[j0 + u], k) : bcast_lane(l, NC + j0 + u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (KIND == CS3_LU) d[j0 + u] -= l * bc[u];
+                else if (lane >= NC + j0 + u) d[j0 + u] -= l * bc[u];
+            }
+        }
+    }
+    eliminate_slice<KIND, NC>(d, NC, keep_unscaled, [](int, double) {});
+}
+
 // Fronts of order 65 .. 136: the front image lives in LDS (one workgroup of 8 waves per front) and is
 // factorised 32 pivots at a time with the same two tools as the big fronts, without leaving the workgroup:
 //   1. eliminate32 -- waves 0..3 stack 32 rows of the block column under the 32 x 32 diagonal block D, waves
@@ -996,6 +1082,8 @@ k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__res
     __shared__ double Bd[BIG_NB][BIG_NB + 1];   // Bd[k][j] = U(kp + k, kb + j)
     __shared__ double D[BIG_NB][BIG_NB + 1];
     __shared__ double T[64][BIG_NB + 1];
+    __shared__ int pair_ready[2];               // eliminate_pair: pivots whose multipliers wave 0 / 1 has handed over
+    if (threadIdx.x < 2) pair_ready[threadIdx.x] = 0;           // (two block barriers lie between this and the first use)
     const FrontDesc d = fdesc[first + blockIdx.z / batch];     // grid (tiles, tiles, fronts * batch)
     const int bz = blockIdx.z % batch;
     const int r = d.r, w = d.w;
@@ -1127,29 +1215,33 @@ k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__res
     }
     __syncthreads();
     CS3_BSTAMP(3);
-    if (tid >= 128) return;                         // waves 0 and 1 carry on: 32 stacked tile rows each
-    const int lane = tid & 63, half = tid >> 6, li = lane & 31;
+    // all four waves carry on: waves 0 and 1 take 32 stacked tile rows each with columns 0..15 of the block, waves 2 and 3
+    // the same rows with columns 16..31 (eliminate_pair).  The multipliers travel through the dead As / Bs buffers.
+    const int lane = tid & 63, half = (tid >> 6) & 1, part = tid >> 7, li = lane & 31;
     const bool stacked = lane >= 32;
     const bool row_tile = (bi == 0 && bj > 0);      // block-row tile (LU only): eliminate D' with tile columns stacked
     const bool diag_tile = (bi == 0 && bj == 0);
     if (diag_tile && half == 1) return;
-    double e[BIG_NB];
+    constexpr int HC = BIG_NB / 2;
+    const int cbase = HC * part;                    // my first column of the block
+    double e[HC];
 #pragma unroll
-    for (int j = 0; j < BIG_NB; ++j) {
-        const double dv = row_tile ? D[j][li] : D[li][j];
-        const double tv = T[32 * half + li][j];
+    for (int j = 0; j < HC; ++j) {
+        const double dv = row_tile ? D[cbase + j][li] : D[li][cbase + j];
+        const double tv = T[32 * half + li][cbase + j];
         e[j] = stacked ? (diag_tile ? 0.0 : tv) : dv;
     }
-    eliminate32<KIND>(e, row_tile);
+    eliminate_pair<KIND>(e, part, row_tile, (half == 0) ? &As[0][0] : &Bs[0][0], &pair_ready[half]);
     CS3_BSTAMP(4);
     CS3_BSTAMP_ROW(6);
     if (diag_tile) {                                // park the factored block, check its pivots
         double *db = dbuf + (long long) (kb / BIG_NB) * (BIG_NB * BIG_NB);
         if (lane < bw) {
 #pragma unroll
-            for (int j = 0; j < BIG_NB; ++j) {
+            for (int jj = 0; jj < HC; ++jj) {
+                const int j = cbase + jj;
                 if (j < bw) {
-                    const double v = e[j];
+                    const double v = e[jj];
                     if (KIND == CS3_LU) {
                         if (lane > j) { if (!(fabs(v) <= inv_tol)) flag_column(status, d.c0 + kb + j); }
                         else if (lane == j) { if (!(fabs(v) > 0.0) || !(fabs(v) < 1.0e300)) flag_column(status, d.c0 + kb + j); }
@@ -1167,17 +1259,20 @@ k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__res
         if (!row_tile) {
             if (tr < nrow) {
 #pragma unroll
-                for (int c = 0; c < BIG_NB; ++c) {
+                for (int cc = 0; cc < HC; ++cc) {
+                    const int c = cbase + cc;
                     if (c < bw) {
-                        if (KIND == CS3_LU && !(fabs(e[c]) <= inv_tol)) flag_column(status, d.c0 + kb + c);
-                        F[(row0 + tr) + (long long) (kb + c) * ld] = e[c];
+                        if (KIND == CS3_LU && !(fabs(e[cc]) <= inv_tol)) flag_column(status, d.c0 + kb + c);
+                        F[(row0 + tr) + (long long) (kb + c) * ld] = e[cc];
                     }
                 }
             }
         } else if (tr < ncol) {
 #pragma unroll
-            for (int c = 0; c < BIG_NB; ++c)
-                if (c < bw) F[(kb + c) + (long long) (col0 + tr) * ld] = e[c];
+            for (int cc = 0; cc < HC; ++cc) {
+                const int c = cbase + cc;
+                if (c < bw) F[(kb + c) + (long long) (col0 + tr) * ld] = e[cc];
+            }
         }
     }
     CS3_BSTAMP(5);

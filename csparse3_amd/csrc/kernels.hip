@@ -326,6 +326,103 @@ front_lds_body(const FrontDesc &d, int first, double *F,
 }
 
 
+constexpr int PAIR_NC = 16;                   // columns per wave of a two-wave elimination (half a 32-pivot block)
+
+// The elimination of eliminate_block (below) on a SLICE of NC columns of the stacked block: d[c] = column c0 + c, whose pivot sits in lane
+// c0 + c (lanes 0..31 are the block's rows, lanes 32..63 the stacked rows).  publish(c, l) receives the multipliers of
+// every pivot as soon as they exist, for the wave that holds the columns to the right (eliminate_pair below).
+// npiv (a front instead of a padded block): only pivots < npiv are eliminated -- the other steps run with zero multipliers
+// rather than behind a branch (a wave-uniform branch per pivot and column group cost the lone wave 200 cycles per pivot).
+// SKIP: steps past npiv are skipped behind one wave-uniform branch each (for a slice nobody waits for: the trailing
+// steps of a front's second half are mostly such steps).
+template <int KIND, int NC, bool SKIP = false, class Publish>
+__device__ __forceinline__ void eliminate_slice(double (&d)[NC], int c0, bool keep_unscaled, Publish publish, int npiv = 1 << 30)
+{
+    constexpr int EB = 8;
+    const int lane = threadIdx.x & 63;
+    const bool stacked = lane >= 32;
+    double piv = bcast_lane(d[0], c0);
+    double dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
+    double rp = fast_rcp(dg);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const int pl = c0 + k;                                  // the pivot's lane
+        if (SKIP && pl >= npiv) continue;
+        const bool below = lane > pl && pl < npiv;
+        const double l = below ? d[k] * rp : 0.0;
+        if (below && !(keep_unscaled && stacked)) d[k] = l;
+        if (KIND == CS3_CHOLESKY && lane == pl && pl < npiv) d[k] = (piv > 0.0) ? dg : -1.0;
+        if (k + 1 < NC) {
+            if (KIND == CS3_LU) d[k + 1] -= l * bcast_lane(d[k + 1], pl);
+            else { const double lj = bcast_lane(d[k], pl + 1); if (lane >= pl + 1) d[k + 1] -= l * lj; }
+            piv = bcast_lane(d[k + 1], pl + 1);
+            dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
+            rp = fast_rcp(dg);
+        }
+        publish(k, l);
+#pragma unroll
+        for (int j0 = k + 2; j0 < NC; j0 += EB) {
+            double bc[EB];
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
+                const int j = j0 + u;
+                if (j < NC) bc[u] = (KIND == CS3_LU) ? bcast_lane(d[j], pl) : bcast_lane(d[k], c0 + j);
+            }
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
+                const int j = j0 + u;
+                if (j < NC) {
+                    if (KIND == CS3_LU) d[j] -= l * bc[u];
+                    else if (lane >= c0 + j) d[j] -= l * bc[u];
+                }
+            }
+        }
+    }
+}
+
+// A stacked 32-pivot elimination by TWO waves: a lone wave spends 425 cycles per pivot on it, nearly all of them issuing
+// two v_readlane and one FMA per column update.  Wave `part` 0 holds columns 0..15 of the 64 rows, wave 1 columns
+// 16..31.  Wave 0 eliminates its 16 pivots and hands the multipliers of each to wave 1 through LDS (lm[k][lane], then
+// *ready = k + 1: LDS operations of a wave complete in order); wave 1 applies them to its columns one pivot behind,
+// then eliminates pivots 16..31 alone.  Wave 0 never waits for wave 1, so the wait below cannot deadlock; it is bounded
+// anyway (a wave that gives up produces a wrong factor, which the residual checks catch, not a hung GPU).
+template <int KIND>
+__device__ __forceinline__ void eliminate_pair(double (&d)[PAIR_NC], int part, bool keep_unscaled, double *lm_generic, volatile int *ready_generic,
+                                               int npiv = 1 << 30)
+{
+    constexpr int NC = PAIR_NC;
+    const int lane = threadIdx.x & 63;
+    // (explicitly LDS: through generic pointers these become flat accesses, and every hand-over waits out a flat store)
+    // volatile on both sides instead of fences: the compiler keeps volatile accesses in program order, the LDS performs a
+    // wave's operations in order -- a release fence after every hand-over (s_waitcnt lgkmcnt(0)) sat on the pivot chain
+    auto *lm = (volatile __attribute__((address_space(3))) double *) lm_generic;
+    auto *ready = (volatile __attribute__((address_space(3))) int *) ready_generic;
+    if (part == 0) {
+        eliminate_slice<KIND, NC>(d, 0, keep_unscaled, [&](int k, double l) {
+            lm[k * 64 + lane] = l;
+            if (lane == 0) *ready = k + 1;
+        }, npiv);
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {                              // (all NC hand-overs happen, with zeros past npiv)
+        for (int it = 0; *ready <= k && it < (1 << 20); ++it) __builtin_amdgcn_s_sleep(1);
+        const double l = lm[k * 64 + lane];                     // zero on and above the pivot row
+#pragma unroll
+        for (int j0 = 0; j0 < NC; j0 += 8) {
+            double bc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bc[u] = (KIND == CS3_LU) ? bcast_lane(d[j0 + u], k) : bcast_lane(l, NC + j0 + u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (KIND == CS3_LU) d[j0 + u] -= l * bc[u];
+                else if (lane >= NC + j0 + u) d[j0 + u] -= l * bc[u];
+            }
+        }
+    }
+    eliminate_slice<KIND, NC, true>(d, NC, keep_unscaled, [](int, double) {}, npiv);
+}
+
 // ---------------------------------------------- front owned by ONE wave ----
 // Fronts of order r <= NC <= 64: lane i keeps ROW i of the front in NC registers, so a pivot
 // needs no barrier and no LDS: the pivot row is read lane-to-scalar (v_readlane) and each lane
@@ -352,6 +449,7 @@ front_wave_body(const FrontDesc &d, int first, double *F,
     CS3_STAMP(0);
     const int nwaves = blockDim.x >> 6;
     for (int i = threadIdx.x; i < r * ld; i += blockDim.x) F[i] = 0.0;
+    if (threadIdx.x == 0 && blockDim.x > 64) *(int *) (F + r * ld + 2 + PAIR_NC * 64) = 0;      // eliminate_pair's counter
     __syncthreads();
     CS3_STAMP(1);
     gather_front(d.asm_begin, d.asm_count >> 6, threadIdx.x >> 6, nwaves,
@@ -367,7 +465,30 @@ front_wave_body(const FrontDesc &d, int first, double *F,
     int bad_col = 0;
     const bool has_parent = d.parent >= 0;
     const bool live = lane < r;
-    if (threadIdx.x < 64) {
+    if (coop && NC == 2 * PAIR_NC) {
+        // four-wave workgroup: waves 0 and 1 eliminate the front together, columns 0..15 and 16..31 (eliminate_pair: a
+        // lone wave is bound by the issue of two v_readlane and one FMA per column update, 470 cycles per pivot)
+        const int part = threadIdx.x >> 6;
+        if (part < 2) {
+            double *lm = F + r * ld + 2;                        // [16][64] multipliers, then the hand-over counter
+            volatile int *ready = (volatile int *) (lm + PAIR_NC * 64);
+            double hrow[PAIR_NC];
+            const int li = lane < r ? lane : 0, c0 = PAIR_NC * part;
+#pragma unroll
+            for (int j = 0; j < PAIR_NC; ++j) {
+                const double v = F[li + (c0 + j < r ? c0 + j : 0) * ld];
+                hrow[j] = (lane < r && c0 + j < r) ? v : 0.0;
+            }
+            CS3_STAMP(3);
+            if (part == 0 || r > PAIR_NC) eliminate_pair<KIND>(hrow, part, false, lm, ready, w);
+            CS3_STAMP(4);
+            if (live) {
+#pragma unroll
+                for (int j = 0; j < PAIR_NC; ++j)
+                    if (c0 + j < r) F[lane + (c0 + j) * ld] = hrow[j];
+            }
+        }
+    } else if (threadIdx.x < 64) {
     double row[NC];
     {
         const int li = lane < r ? lane : 0;             // unconditional LDS reads, then select
@@ -529,6 +650,7 @@ k_front_mix(const FrontDesc *__restrict__ fdesc, int first,
 // of BIG_NB pivots a panel launch and a trailing-update launch -- a blocked
 // right-looking LU / Cholesky without pivoting, many workgroups per launch.
 constexpr int BIG_NB = 32;
+static_assert(BIG_NB == 2 * PAIR_NC, "eliminate_pair splits a block of BIG_NB pivots in two");
 
 __global__ void __launch_bounds__(256)
 k_big_gather(const FrontDesc *__restrict__ fdesc, int first,
@@ -606,91 +728,6 @@ __device__ __forceinline__ void eliminate_block(double (&d)[NBK], bool keep_unsc
 template <int KIND>
 __device__ __forceinline__ void eliminate32(double (&d)[BIG_NB], bool keep_unscaled) { eliminate_block<KIND, BIG_NB>(d, keep_unscaled); }
 
-// The same elimination on a SLICE of NC columns of the stacked block: d[c] = column c0 + c, whose pivot sits in lane
-// c0 + c (lanes 0..31 are the block's rows, lanes 32..63 the stacked rows).  publish(c, l) receives the multipliers of
-// every pivot as soon as they exist, for the wave that holds the columns to the right (eliminate_pair below).
-template <int KIND, int NC, class Publish>
-__device__ __forceinline__ void eliminate_slice(double (&d)[NC], int c0, bool keep_unscaled, Publish publish)
-{
-    constexpr int EB = 8;
-    const int lane = threadIdx.x & 63;
-    const bool stacked = lane >= 32;
-    double piv = bcast_lane(d[0], c0);
-    double dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
-    double rp = fast_rcp(dg);
-#pragma unroll
-    for (int k = 0; k < NC; ++k) {
-        const int pl = c0 + k;                                  // the pivot's lane
-        const bool below = lane > pl;
-        const double l = below ? d[k] * rp : 0.0;
-        if (below && !(keep_unscaled && stacked)) d[k] = l;
-        if (KIND == CS3_CHOLESKY && lane == pl) d[k] = (piv > 0.0) ? dg : -1.0;
-        if (k + 1 < NC) {
-            if (KIND == CS3_LU) d[k + 1] -= l * bcast_lane(d[k + 1], pl);
-            else { const double lj = bcast_lane(d[k], pl + 1); if (lane >= pl + 1) d[k + 1] -= l * lj; }
-            piv = bcast_lane(d[k + 1], pl + 1);
-            dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
-            rp = fast_rcp(dg);
-        }
-        publish(k, l);
-#pragma unroll
-        for (int j0 = k + 2; j0 < NC; j0 += EB) {
-            double bc[EB];
-#pragma unroll
-            for (int u = 0; u < EB; ++u) {
-                const int j = j0 + u;
-                if (j < NC) bc[u] = (KIND == CS3_LU) ? bcast_lane(d[j], pl) : bcast_lane(d[k], c0 + j);
-            }
-#pragma unroll
-            for (int u = 0; u < EB; ++u) {
-                const int j = j0 + u;
-                if (j < NC) {
-                    if (KIND == CS3_LU) d[j] -= l * bc[u];
-                    else if (lane >= c0 + j) d[j] -= l * bc[u];
-                }
-            }
-        }
-    }
-}
-
-// A stacked 32-pivot elimination by TWO waves: a lone wave spends 425 cycles per pivot on it, nearly all of them issuing
-// two v_readlane and one FMA per column update.  Wave `part` 0 holds columns 0..15 of the 64 rows, wave 1 columns
-// 16..31.  Wave 0 eliminates its 16 pivots and hands the multipliers of each to wave 1 through LDS (lm[k][lane], then
-// *ready = k + 1: LDS operations of a wave complete in order); wave 1 applies them to its columns one pivot behind,
-// then eliminates pivots 16..31 alone.  Wave 0 never waits for wave 1, so the wait below cannot deadlock; it is bounded
-// anyway (a wave that gives up produces a wrong factor, which the residual checks catch, not a hung GPU).
-template <int KIND>
-__device__ __forceinline__ void eliminate_pair(double (&d)[BIG_NB / 2], int part, bool keep_unscaled, double *lm, volatile int *ready)
-{
-    constexpr int NC = BIG_NB / 2;
-    const int lane = threadIdx.x & 63;
-    if (part == 0) {
-        eliminate_slice<KIND, NC>(d, 0, keep_unscaled, [&](int k, double l) {
-            lm[k * 64 + lane] = l;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) *ready = k + 1;
-        });
-        return;
-    }
-#pragma unroll
-    for (int k = 0; k < NC; ++k) {
-        for (int it = 0; *ready <= k && it < (1 << 20); ++it) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const double l = lm[k * 64 + lane];                     // zero on and above the pivot row
-#pragma unroll
-        for (int j0 = 0; j0 < NC; j0 += 8) {
-            double bc[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) bc[u] = (KIND == CS3_LU) ? bcast_lane(d[j0 + u], k) : bcast_lane(l, NC + j0 + u);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (KIND == CS3_LU) d[j0 + u] -= l * bc[u];
-                else if (lane >= NC + j0 + u) d[j0 + u] -= l * bc[u];
-            }
-        }
-    }
-    eliminate_slice<KIND, NC>(d, NC, keep_unscaled, [](int, double) {});
-}
 
 // Fronts of order 65 .. 136: the front image lives in LDS (one workgroup of 8 waves per front) and is
 // factorised 32 pivots at a time with the same two tools as the big fronts, without leaving the workgroup:
@@ -1222,7 +1259,7 @@ k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__res
     const bool row_tile = (bi == 0 && bj > 0);      // block-row tile (LU only): eliminate D' with tile columns stacked
     const bool diag_tile = (bi == 0 && bj == 0);
     if (diag_tile && half == 1) return;
-    constexpr int HC = BIG_NB / 2;
+    constexpr int HC = PAIR_NC;
     const int cbase = HC * part;                    // my first column of the block
     double e[HC];
 #pragma unroll
@@ -3304,8 +3341,8 @@ static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g
     case FC_R16:
     case FC_R32:      // only present when the analysis split the small fronts off (batched handles)
         hipLaunchKernelGGL((k_front_wave<KIND>), grid, dim3(64), lds, st, CS3_FRONT_ARGS); break;
-    case FC_R64:
-        hipLaunchKernelGGL((k_front_mix<KIND>), grid, dim3(256), lds, st, CS3_FRONT_ARGS); break;
+    case FC_R64:      // (+ the multipliers and the counter of the two-wave elimination behind the image)
+        hipLaunchKernelGGL((k_front_mix<KIND>), grid, dim3(256), lds + (PAIR_NC * 64 + 2) * sizeof(double), st, CS3_FRONT_ARGS); break;
     default:
         // pivots per block step: the one-wave elimination of a block costs NBK^2 column updates, the MFMA update that
         // follows is cheap, so narrow blocks win (measured: 32 -> 16 took 4 % off the batched config, neutral on config 3)

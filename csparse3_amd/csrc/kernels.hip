@@ -423,6 +423,50 @@ __device__ __forceinline__ void eliminate_pair(double (&d)[PAIR_NC], int part, b
     eliminate_slice<KIND, NC, true>(d, NC, keep_unscaled, [](int, double) {}, npiv);
 }
 
+// The same hand-over for a front of order <= 64 split over up to four waves: wave `part` holds columns
+// [16 part, 16 part + 16) of all 64 rows (lane = row).  It applies the multipliers of the pivots to its left as they
+// appear (lm[g][lane], *ready = pivots published so far: pivots are published strictly in order, so one counter serves
+// all producers), then eliminates its own pivots and publishes them.  Only pivots < npiv exist; wave 0 publishes all 16
+// of its steps (zeros past npiv) so that it runs without a branch, the others publish the real ones only.
+template <int KIND>
+__device__ __forceinline__ void eliminate_parts(double (&d)[PAIR_NC], int part, int nparts, double *lm_generic, int *ready_generic, int npiv)
+{
+    constexpr int NC = PAIR_NC;
+    const int lane = threadIdx.x & 63;
+    auto *lm = (volatile __attribute__((address_space(3))) double *) lm_generic;
+    auto *ready = (volatile __attribute__((address_space(3))) int *) ready_generic;
+    const int c0 = NC * part;
+    // blocks of 16 pivots to my left, whole blocks only (one branch per block, none per pivot: a block that holds a real
+    // pivot was published in full, with zero multipliers past npiv)
+    for (int g0 = 0; g0 < c0 && g0 < npiv; g0 += NC) {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int g = g0 + k;
+            for (int it = 0; *ready <= g && it < (1 << 20); ++it) __builtin_amdgcn_s_sleep(1);
+            const double l = lm[g * 64 + lane];                 // zero on and above the pivot row
+#pragma unroll
+            for (int j0 = 0; j0 < NC; j0 += 8) {
+                double bc[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) bc[u] = (KIND == CS3_LU) ? bcast_lane(d[j0 + u], g) : bcast_lane(l, c0 + j0 + u);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (KIND == CS3_LU) d[j0 + u] -= l * bc[u];
+                    else if (lane >= c0 + j0 + u) d[j0 + u] -= l * bc[u];
+                }
+            }
+        }
+    }
+    if (c0 >= npiv) return;                                     // no pivot of mine exists
+    auto publish = [&](int k, double l) {
+        lm[(c0 + k) * 64 + lane] = l;
+        if (lane == 0) *ready = c0 + k + 1;
+    };
+    // a wave with consumers to its right runs all 16 steps without a branch; the last one skips the steps past npiv
+    if (part + 1 < nparts) eliminate_slice<KIND, NC, false>(d, c0, false, publish, npiv);
+    else eliminate_slice<KIND, NC, true>(d, c0, false, [](int, double) {}, npiv);
+}
+
 // ---------------------------------------------- front owned by ONE wave ----
 // Fronts of order r <= NC <= 64: lane i keeps ROW i of the front in NC registers, so a pivot
 // needs no barrier and no LDS: the pivot row is read lane-to-scalar (v_readlane) and each lane
@@ -449,7 +493,7 @@ front_wave_body(const FrontDesc &d, int first, double *F,
     CS3_STAMP(0);
     const int nwaves = blockDim.x >> 6;
     for (int i = threadIdx.x; i < r * ld; i += blockDim.x) F[i] = 0.0;
-    if (threadIdx.x == 0 && blockDim.x > 64) *(int *) (F + r * ld + 2 + PAIR_NC * 64) = 0;      // eliminate_pair's counter
+    if (threadIdx.x == 0 && blockDim.x > 64) *(int *) (F + r * ld + 2) = 0;                     // eliminate_parts' counter
     __syncthreads();
     CS3_STAMP(1);
     gather_front(d.asm_begin, d.asm_count >> 6, threadIdx.x >> 6, nwaves,
@@ -465,13 +509,14 @@ front_wave_body(const FrontDesc &d, int first, double *F,
     int bad_col = 0;
     const bool has_parent = d.parent >= 0;
     const bool live = lane < r;
-    if (coop && NC == 2 * PAIR_NC) {
-        // four-wave workgroup: waves 0 and 1 eliminate the front together, columns 0..15 and 16..31 (eliminate_pair: a
-        // lone wave is bound by the issue of two v_readlane and one FMA per column update, 470 cycles per pivot)
+    if (coop) {
+        // four-wave workgroup, front of order <= 64: wave `part` takes columns [16 part, 16 part + 16) of all rows
+        // (eliminate_parts: a lone wave is bound by the issue of two v_readlane and one FMA per column update, 470 cycles
+        // per pivot; the 16 x 16 thread grid that used to serve the orders 33..64 paid two block barriers per pivot)
         const int part = threadIdx.x >> 6;
-        if (part < 2) {
-            double *lm = F + r * ld + 2;                        // [16][64] multipliers, then the hand-over counter
-            volatile int *ready = (volatile int *) (lm + PAIR_NC * 64);
+        if (PAIR_NC * part < r) {
+            int *ready = (int *) (F + r * ld + 2);              // pivots handed over so far, then [pivots][64] multipliers
+            double *lm = F + r * ld + 4;
             double hrow[PAIR_NC];
             const int li = lane < r ? lane : 0, c0 = PAIR_NC * part;
 #pragma unroll
@@ -480,7 +525,7 @@ front_wave_body(const FrontDesc &d, int first, double *F,
                 hrow[j] = (lane < r && c0 + j < r) ? v : 0.0;
             }
             CS3_STAMP(3);
-            if (part == 0 || r > PAIR_NC) eliminate_pair<KIND>(hrow, part, false, lm, ready, w);
+            eliminate_parts<KIND>(hrow, part, (r + PAIR_NC - 1) / PAIR_NC, lm, ready, w);
             CS3_STAMP(4);
             if (live) {
 #pragma unroll
@@ -631,12 +676,12 @@ __global__ void __launch_bounds__(256)
 k_front_mix(const FrontDesc *__restrict__ fdesc, int first,
             const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
             const double *__restrict__ ax_all, double *__restrict__ pool_all,
-            long long nnz_a, long long pool_stride, IlView il, double inv_tol, int *status, long long *tbuf)
+            long long nnz_a, long long pool_stride, IlView il, double inv_tol, int *status, long long *tbuf, int lds_grid)
 {
     extern __shared__ __attribute__((aligned(16))) double F[];
     const long long t_start = tbuf ? (long long) __builtin_amdgcn_s_memtime() : 0;
     const FrontDesc d = fdesc[first + blockIdx.x];
-    if (d.r <= 32)
+    if (!lds_grid || d.r <= 32)         // (four waves: the cooperative path of front_wave_body serves every order <= 64)
         front_wave_body<KIND, 32>(d, first, F, asm_src, asm_tgt, long_src, ax_all, pool_all, nnz_a, pool_stride, il,
                                   inv_tol, status, tbuf, t_start);
     else
@@ -1797,7 +1842,8 @@ k_fwd_blk(const SolveDesc *__restrict__ sd, int first,
             const int i = kb + lane;
             if (kb > 0) tri.load(L, r, kb, bw);    // (the first one came in with the assembly)
             const double vi = tri.solve((lane < bw) ? v[i] : 0.0, bw);
-            if (lane < bw) { v[i] = vi; y[lane] = vi; }
+            if (lane < bw) v[i] = vi;
+            y[lane] = (lane < bw) ? vi : 0.0;      // all 64: the products below run over the whole chunk (0 x stale LDS is not 0)
         }
         __syncthreads();
         for (int i = kb + bw + tid; i < r; i += 256) {      // rows below the chunk
@@ -1883,7 +1929,8 @@ k_bwd_blk(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ s
             const int i = kb + lane;
             if (c < nchunk - 1) tri.load(L, r, kb, bw);     // (the rightmost one came in with the front vector)
             const double vi = tri.solve((lane < bw) ? v[i] : 0.0, bw);
-            if (lane < bw) { v[i] = vi; y[lane] = vi; }
+            if (lane < bw) v[i] = vi;
+            y[lane] = (lane < bw) ? vi : 0.0;      // all 64 (see k_fwd_blk)
         }
         __syncthreads();
         for (int i = tid; i < kb; i += 256) {      // pivot rows above the chunk
@@ -1970,7 +2017,7 @@ k_fwd_big_step(const SolveDesc *__restrict__ sd, int first, int kb,
         BlockTriangle<KIND, true> ta;
         ta.load(L, r, kb, bwa);
         const double vi = ta.solve(load_if(v, kb + lane, lane < bwa), bwa);
-        if (lane < bwa) y[lane] = vi;
+        y[lane] = (lane < bwa) ? vi : 0.0;          // all 64: wave 2 multiplies the whole block (0 x stale LDS is not 0)
         __syncthreads();
         __syncthreads();
     } else if (wv == 1) {                           // second block: its triangle; the first block's solution reaches its
@@ -3341,8 +3388,14 @@ static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g
     case FC_R16:
     case FC_R32:      // only present when the analysis split the small fronts off (batched handles)
         hipLaunchKernelGGL((k_front_wave<KIND>), grid, dim3(64), lds, st, CS3_FRONT_ARGS); break;
-    case FC_R64:      // (+ the multipliers and the counter of the two-wave elimination behind the image)
-        hipLaunchKernelGGL((k_front_mix<KIND>), grid, dim3(256), lds + (PAIR_NC * 64 + 2) * sizeof(double), st, CS3_FRONT_ARGS); break;
+    case FC_R64: {    // (+ the counter and the multipliers of the shared elimination behind the image: [pivots][64])
+        // orders 33..64: the 16 x 16 thread grid (front_lds_body).  CS3_LDS_GRID=0 sends them through the shared elimination
+        // too (four waves x 16 columns): equal on config 3 (their level is set by the assembly), 3.99 against 3.57 ms on 512
+        // batched matrices -- waves that wait for multipliers take issue slots from the other fronts of a full CU
+        static const int lds_grid = !(getenv("CS3_LDS_GRID") && getenv("CS3_LDS_GRID")[0] == '0');
+        const size_t lm = (size_t) 64 * ((std::min(g.max_w, 64) + PAIR_NC - 1) / PAIR_NC * PAIR_NC) + 4;
+        hipLaunchKernelGGL((k_front_mix<KIND>), grid, dim3(256), lds + lm * sizeof(double), st, CS3_FRONT_ARGS, lds_grid); break;
+    }
     default:
         // pivots per block step: the one-wave elimination of a block costs NBK^2 column updates, the MFMA update that
         // follows is cheap, so narrow blocks win (measured: 32 -> 16 took 4 % off the batched config, neutral on config 3)

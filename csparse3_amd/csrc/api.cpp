@@ -194,7 +194,8 @@ int ensure_device_impl(cs3_handle h)
     D.pool_pm = D.pool + il_doubles - D.il_len;            // virtual offsets >= il_len index this pointer directly
     CS3_HIP(hipMalloc((void **) &D.dbuf, std::max<size_t>(1, (size_t) (D.batch * D.dbuf_size)) * sizeof(double)));
     CS3_HIP(hipMalloc((void **) &D.ax, std::max<size_t>(1, (size_t) (D.batch * D.nnz_a)) * sizeof(double)));
-    CS3_HIP(hipMalloc((void **) &D.status, sizeof(int)));
+    CS3_HIP(hipMalloc((void **) &D.status, 4 * sizeof(int)));    // [0] the status word, [1], [2] hand-over words of the fused step (k_flag_wait)
+    CS3_HIP(hipMemset(D.status, 0, 4 * sizeof(int)));
     CS3_HIP(hipMemset(D.status, 0x7f, sizeof(int)));      // "clean": a handle that only imports factors never runs a prologue
     if (const char *pf = std::getenv("CS3_PROFILE")) {
         if (pf[0] == '1') {
@@ -274,9 +275,16 @@ int run_factor(cs3_handle h, const double *ax_dev, double tol, hipStream_t st)
 
 int read_status(cs3_handle h, hipStream_t st)
 {
-    int col = 0;
-    CS3_HIP(hipMemcpyAsync(&col, h->D.status, sizeof(int), hipMemcpyDeviceToHost, st));
+    int word[4] = {0, 0, 0, 0};
+    CS3_HIP(hipMemcpyAsync(word, h->D.status, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
     CS3_HIP(hipStreamSynchronize(st));
+    if (word[3] != 0) {               // a hand-over of the fused step timed out (k_flag_wait): its sweep ran unsynchronised
+        CS3_HIP(hipMemsetAsync(h->D.status + 3, 0, sizeof(int), st));
+        h->factored = false;
+        set_error("fused factor + solve: the side queue gave up waiting for the factorisation (set CS3_FLAG_SYNC=0)");
+        return CS3_ERR_STATE;
+    }
+    const int col = word[0];
     if (col == 0x7f7f7f7f) { h->fail_col = -1; return CS3_OK; }
     h->fail_col = col;
     h->factored = false;

@@ -85,7 +85,7 @@ struct DeviceFactor {
     bool inverses_in_sweep = false;   // the forward sweep computes them group by group (fused factor + solve graph)
     XMap xm;                          // what the sweeps captured / launched next should use (set by the caller)
     long long nrhs_cap = 0;
-    int *status = nullptr;        // [1] first failing pivot column, 0x7f7f7f7f when clean
+    int *status = nullptr;        // [0] first failing pivot column, 0x7f7f7f7f when clean; [1], [2]: hand-over words of the fused step
     long long *tbuf = nullptr;    // diagnostics (CS3_PROFILE=1): 8 shader-clock stamps per front, schedule order
 };
 

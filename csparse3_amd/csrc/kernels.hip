@@ -701,8 +701,11 @@ __global__ void __launch_bounds__(256)
 k_big_gather(const FrontDesc *__restrict__ fdesc, int first,
              const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
              const double *__restrict__ ax_all, double *__restrict__ pool_all,
-             long long nnz_a, long long pool_stride, IlView il)
+             long long nnz_a, long long pool_stride, IlView il, int *signal)
 {
+    // (fused step: everything launched before this kernel on its stream is complete -- tell the side queue, k_flag_wait)
+    if (signal && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        __hip_atomic_store(signal, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     const FrontDesc d = fdesc[first + blockIdx.z];
     const double *pil = il_lane_base(il, blockIdx.y);
     const double *ax = ax_all + (long long) blockIdx.y * nnz_a;
@@ -1149,8 +1152,10 @@ template <int KIND>
 __global__ void __launch_bounds__(256)
 k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__restrict__ pool_all,
            long long pool_stride, double *__restrict__ dbuf_all, long long dbuf_stride,
-           double inv_tol, int *status, int batch, long long *tbuf)
+           double inv_tol, int *status, int batch, long long *tbuf, int *signal)
 {
+    if (signal && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)      // (see k_big_gather)
+        __hip_atomic_store(signal, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     // diagnostics (CS3_PROFILE=1): block-column tile (1, 0) of the step kb == 64 stamps its phases into the front's slot
     const long long t_start = tbuf ? (long long) __builtin_amdgcn_s_memtime() : 0;
 #define CS3_BSTAMP(p) do { if (tbuf && kb == 64 && blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0) \
@@ -3090,7 +3095,7 @@ k_prologue(int *status, double *__restrict__ pool, long long big_begin, long lon
            const double *__restrict__ x_src, double *__restrict__ xp, const int *__restrict__ q, long long n, int nrhs)
 {
     const long long t0 = (long long) blockIdx.x * blockDim.x + threadIdx.x, stride = (long long) gridDim.x * blockDim.x;
-    if (t0 == 0) *status = 0x7f7f7f7f;
+    if (t0 == 0) { status[0] = 0x7f7f7f7f; status[1] = 0; status[2] = 0; }      // ... and the two hand-over words of the fused step
     const long long z_all = nzero * batch, x_all = x_src ? n * nrhs * batch : 0;
     for (long long t = t0; t < z_all + nax + x_all; t += stride) {
         if (t < z_all) {
@@ -3310,18 +3315,18 @@ static int grid_for(long long work, int block, int cap = 4096)
 // A group of big fronts = one gather launch, then launches 0 .. nblk of the block step (nblk = closing).
 static int big_group_blocks(const LaunchGroup &g) { return (g.max_w + BIG_NB - 1) / BIG_NB; }
 
-static hipError_t launch_big_gather(const DeviceFactor &D, const LaunchGroup &g, hipStream_t st)
+static hipError_t launch_big_gather(const DeviceFactor &D, const LaunchGroup &g, hipStream_t st, int *signal = nullptr)
 {
     const int chunks = (int) (g.max_asm >> 6);
     const int gx = std::max(1, std::min(64, (chunks + 4 * GATHER_UNROLL - 1) / (4 * GATHER_UNROLL)));
     hipLaunchKernelGGL(k_big_gather, dim3(gx, (unsigned) D.batch, g.count), dim3(256), 0, st, D.fdesc, g.first,
-                       D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool_pm, D.nnz_a, D.pm_stride, IlView{D.pool_il, D.il_len});
+                       D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool_pm, D.nnz_a, D.pm_stride, IlView{D.pool_il, D.il_len}, signal);
     CS3_LAUNCH_CHECK();
     return hipSuccess;
 }
 
 template <int KIND>
-static hipError_t launch_big_block(const DeviceFactor &D, const LaunchGroup &g, int blk, double inv_tol, hipStream_t st)
+static hipError_t launch_big_block(const DeviceFactor &D, const LaunchGroup &g, int blk, double inv_tol, hipStream_t st, int *signal = nullptr)
 {
     const unsigned batch = (unsigned) D.batch;
     const int kb = blk * BIG_NB;
@@ -3331,7 +3336,7 @@ static hipError_t launch_big_block(const DeviceFactor &D, const LaunchGroup &g, 
     const int rem = g.max_r - std::min(start, g.max_r);        // largest trailing order over the group
     const int tiles = 1 + (rem + 63) / 64;
     hipLaunchKernelGGL((k_big_step<KIND>), dim3(tiles, tiles, g.count * batch), dim3(256), 0, st, D.fdesc,
-                       g.first, kb, D.pool_pm, D.pm_stride, D.dbuf, D.dbuf_size, inv_tol, D.status, (int) batch, D.tbuf);
+                       g.first, kb, D.pool_pm, D.pm_stride, D.dbuf, D.dbuf_size, inv_tol, D.status, (int) batch, D.tbuf, signal);
     CS3_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -3876,6 +3881,23 @@ hipError_t launch_solve_levels(const DeviceFactor &D, const std::vector<LaunchGr
     return hipSuccess;
 }
 
+// The overlapped forward sweep does not wait for the factorisation through a cross-queue dependency of the graph: the
+// first dispatch of the side queue then comes 130-200 us after the dependency is met (measured; the main queue keeps
+// dispatching block steps meanwhile), which made the sweep the longer branch once the root's block steps had become
+// faster.  Its branch starts with the graph instead and holds a one-thread kernel that waits for a word in memory, which
+// the first launch AFTER the awaited point sets as it starts (k_big_gather / k_big_step, thread 0): a few microseconds from
+// flag to sweep.  The waiter consumes the flag (1 -> 0; the prologue clears both words anyway) and gives up after about a
+// second -- a sweep that started early gives a wrong answer, not a hung GPU.
+__global__ void k_flag_wait(int *flag, int *timed_out)
+{
+    for (long long it = 0; it < (1ll << 22); ++it) {
+        int expected = 1;
+        if (__hip_atomic_compare_exchange_strong(flag, &expected, 0, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    *timed_out = 1;                                  // read_status reports it: the results of this step are not to be used
+}
+
 // Rough cost of a launch group in dependent-launch units, to place the fork below.
 static int factor_group_cost(const LaunchGroup &g)
 {
@@ -3936,6 +3958,15 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
     }
     hipEvent_t swept = nullptr, ready_deferred = nullptr;
     static const bool sweep_first = getenv("CS3_SWEEP_FIRST") && getenv("CS3_SWEEP_FIRST")[0] == '1';   // the round-1 capture order
+    // hand-overs to the side queue through memory words instead of graph dependencies (k_flag_wait), pipelined root only
+    static const bool flag_env = !(getenv("CS3_FLAG_SYNC") && getenv("CS3_FLAG_SYNC")[0] == '0');
+    const bool flags = flag_env && rootf && !sweep_first && nlevels >= 3;
+    int *flag_ready = D.status + 1, *flag_home = D.status + 2;
+    // the side branch forks after the first level and is captured after the second: captured first it would take the
+    // graph's primary hardware queue and the factorisation the slow one (capture order, above)
+    hipEvent_t begin = nullptr;
+    int levels_done = 0;
+
     int root_rest = 0;                             // first chunk of the root's sweep that is still to do after the join
     for (size_t f0 = 0; f0 < fgroups.size(); ) {
         const int level = fgroups[f0].level;
@@ -3944,7 +3975,7 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
         if (rootf && level == nlevels - 1) {
             const BigSweepPlan pl = big_sweep_plan(D, *roots, nrhs);
             const int nblk = big_group_blocks(*rootf), cwb = pl.cw / BIG_NB;
-            if ((e = launch_big_gather(D, *rootf, st)) != hipSuccess) return e;
+            if ((e = launch_big_gather(D, *rootf, st, flags ? flag_ready : nullptr)) != hipSuccess) return e;
             // ONE release (every cross-stream edge costs the block chain about 10 us): the first k chunks go to
             // fj.aux after block launch k * cwb, k the largest count that the remaining launches still cover;
             // the other chunks follow on st after the join.
@@ -3965,7 +3996,10 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
             bool side_started = false;
             auto start_side = [&]() -> hipError_t {                        // sweep of the lower levels + the root's gather
                 side_started = true;
-                if (ready_deferred) {
+                if (flags) {                                               // (fj.aux already holds the waiting kernel)
+                    hipError_t se;
+                    if ((se = sweep(0, fork_level, fj.aux)) != hipSuccess) return se;
+                } else if (ready_deferred) {
                     hipError_t se;
                     if ((se = hipStreamWaitEvent(fj.aux, ready_deferred, 0)) != hipSuccess) return se;
                     if ((se = sweep(0, fork_level, fj.aux)) != hipSuccess) return se;
@@ -3974,7 +4008,10 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
             };
             auto release = [&]() -> hipError_t {                           // chunks 0 .. k - 1 hang off block launch k * cwb
                 hipError_t se;
-                if ((se = hipStreamWaitEvent(fj.aux, home, 0)) != hipSuccess) return se;
+                if (flags) {
+                    hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(1), 0, fj.aux, flag_home, D.status + 3);
+                    if ((se = hipGetLastError()) != hipSuccess) return se;
+                } else if ((se = hipStreamWaitEvent(fj.aux, home, 0)) != hipSuccess) return se;
                 for (int c = 0; c < k; ++c) {
                     se = (D.kind == CS3_LU) ? launch_fwd_big_chunk<CS3_LU>(D, *roots, X, nrhs, c, fj.aux)
                                             : launch_fwd_big_chunk<CS3_CHOLESKY>(D, *roots, X, nrhs, c, fj.aux);
@@ -3995,8 +4032,10 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
                     if ((e = hipEventRecord(pre, fj.aux)) != hipSuccess) return e;
                     if ((e = hipStreamWaitEvent(st, pre, 0)) != hipSuccess) return e;
                 }
-                e = (D.kind == CS3_LU) ? launch_big_block<CS3_LU>(D, *rootf, blk, inv_tol, st)
-                                       : launch_big_block<CS3_CHOLESKY>(D, *rootf, blk, inv_tol, st);
+                // (blocks 0 .. k cwb - 1 are home when launch k cwb is complete, i.e. when launch k cwb + 1 starts: it says so)
+                int *sig = (flags && k > 0 && blk == k * cwb + 1) ? flag_home : nullptr;
+                e = (D.kind == CS3_LU) ? launch_big_block<CS3_LU>(D, *rootf, blk, inv_tol, st, sig)
+                                       : launch_big_block<CS3_CHOLESKY>(D, *rootf, blk, inv_tol, st, sig);
                 if (e != hipSuccess) return e;
                 if (!side_started && (e = start_side()) != hipSuccess) return e;      // after the chain's first block is captured
                 if (home && (e = release()) != hipSuccess) return e;                  // after the block that follows the release point
@@ -4017,6 +4056,14 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
                                       : launch_front_group<CS3_CHOLESKY>(D, g, inv_tol, s);
         });
         if (e != hipSuccess) return e;
+        if (flags && ++levels_done == 1) {             // (as a root node of the graph, captured here: no better, 0.632 vs 0.628 ms)
+            if ((e = fj.event(&begin)) != hipSuccess) return e;
+            if ((e = hipEventRecord(begin, st)) != hipSuccess) return e;
+        } else if (flags && levels_done == 2) {
+            if ((e = hipStreamWaitEvent(fj.aux, begin, 0)) != hipSuccess) return e;
+            hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(1), 0, fj.aux, flag_ready, D.status + 3);
+            CS3_LAUNCH_CHECK();
+        }
         if (ready_deferred && !rootf) {            // the level above the fork has been captured: now the side branch
             if ((e = hipStreamWaitEvent(fj.aux, ready_deferred, 0)) != hipSuccess) return e;
             if ((e = sweep(0, fork_level, fj.aux)) != hipSuccess) return e;

@@ -1851,11 +1851,15 @@ k_fwd_blk(const SolveDesc *__restrict__ sd, int first,
             y[lane] = (lane < bw) ? vi : 0.0;      // all 64: the products below run over the whole chunk (0 x stale LDS is not 0)
         }
         __syncthreads();
-        for (int i = kb + bw + tid; i < r; i += 256) {      // rows below the chunk
+        for (int i = kb + bw + tid; i < r; i += 256) {      // rows below the chunk, 16 columns of it per round trip
             double acc = 0.0;
-#pragma unroll 16
-            for (int j = 0; j < SOLVE_BW; ++j)
-                acc += load_if(L, i + (long long) (kb + j) * r, j < bw) * y[j];
+            for (int j0 = 0; j0 < bw; j0 += 16) {
+                double lv[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) lv[j] = load_if(L, i + (long long) (kb + j0 + j) * r, j0 + j < bw);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc += lv[j] * y[j0 + j];
+            }
             v[i] -= acc;
         }
         __syncthreads();
@@ -1940,11 +1944,16 @@ k_bwd_blk(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ s
         __syncthreads();
         for (int i = tid; i < kb; i += 256) {      // pivot rows above the chunk
             double acc = 0.0;
-#pragma unroll 16
-            for (int j = 0; j < SOLVE_BW; ++j) {
-                const long long off = (KIND == CS3_LU) ? (long long) i + (long long) (kb + j) * r
-                                                       : (long long) (kb + j) + (long long) i * r;
-                acc += load_if(L, off, j < bw) * y[j];
+            for (int j0 = 0; j0 < bw; j0 += 16) {
+                double uv[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const long long off = (KIND == CS3_LU) ? (long long) i + (long long) (kb + j0 + j) * r
+                                                           : (long long) (kb + j0 + j) + (long long) i * r;
+                    uv[j] = load_if(L, off, j0 + j < bw);
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc += uv[j] * y[j0 + j];
             }
             v[i] -= acc;
         }
@@ -1970,9 +1979,12 @@ k_fwd_big_gather(const SolveDesc *__restrict__ sd, int first,
     const double *cv = cv_all + (long long) b * cv_stride;
     const double *X = X_all + (long long) b * x_stride;
     double *v = bigv_all + ((long long) b * nrhs + rhs) * bv_size + d.bv;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    // rows without any source (none in practice: every row has X or a child) keep what the init wrote
-    gather_front(d.fasm_begin, d.fasm_count >> 6, wave, gridDim.x * 4, fsrc, ftgt, flong,
+    // one workgroup per front vector: rows that no child updates have no source in the gather list and start from zero
+    // (the zeroing was a hipMemsetAsync before the launch: two fill kernels, 10 us on the overlapped sweep's branch)
+    for (int i = threadIdx.x; i < d.r; i += 256) v[i] = 0.0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6;
+    gather_front(d.fasm_begin, d.fasm_count >> 6, wave, 4, fsrc, ftgt, flong,
                  [&](int q) -> const double * {
                      return (q >= 0) ? cv + (long long) q * nrhs + rhs : X + (long long) (~q) * nrhs + rhs;
                  },
@@ -3563,10 +3575,7 @@ static BigSweepPlan big_sweep_plan(const DeviceFactor &D, const LaunchGroup &g, 
 static hipError_t launch_fwd_big_pre(const DeviceFactor &D, const LaunchGroup &g, double *X, int nrhs, hipStream_t st)
 {
     const BigSweepPlan pl = big_sweep_plan(D, g, nrhs);
-    // rows that no child updates have no source in the gather list: start from zero
-    hipError_t me = hipMemsetAsync(D.bigv, 0, (size_t) (D.batch * nrhs * D.bv_size) * sizeof(double), st);
-    if (me != hipSuccess) return me;
-    hipLaunchKernelGGL(k_fwd_big_gather, dim3(4, pl.by, g.count), dim3(256), 0, st, D.sdesc, g.first, D.fasm_src,
+    hipLaunchKernelGGL(k_fwd_big_gather, dim3(1, pl.by, g.count), dim3(256), 0, st, D.sdesc, g.first, D.fasm_src,
                        D.fasm_tgt, D.flong_src, D.cv, X, D.bigv, nrhs, D.cv_size * (long long) nrhs, D.n * (long long) nrhs, D.bv_size);
     CS3_LAUNCH_CHECK();
     return hipSuccess;

@@ -281,7 +281,7 @@ int read_status(cs3_handle h, hipStream_t st)
     if (word[3] != 0) {               // a hand-over of the fused step timed out (k_flag_wait): its sweep ran unsynchronised
         CS3_HIP(hipMemsetAsync(h->D.status + 3, 0, sizeof(int), st));
         h->factored = false;
-        set_error("fused factor + solve: the side queue gave up waiting for the factorisation (set CS3_FLAG_SYNC=0)");
+        set_error("fused factor + solve: the side queue gave up waiting for the factorisation (CS3_FLAG_SYNC=1 needs concurrent queues: unset it under tools that serialise kernels)");
         return CS3_ERR_STATE;
     }
     const int col = word[0];

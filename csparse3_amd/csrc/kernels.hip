@@ -16,6 +16,8 @@
 // No float atomics anywhere: children are added in a fixed order, so results
 // are bitwise reproducible run to run.
 #include <hip/hip_runtime.h>
+
+
 #include <stdint.h>
 
 #include <algorithm>
@@ -3899,7 +3901,7 @@ hipError_t launch_solve_levels(const DeviceFactor &D, const std::vector<LaunchGr
 // second -- a sweep that started early gives a wrong answer, not a hung GPU.
 __global__ void k_flag_wait(int *flag, int *timed_out)
 {
-    for (long long it = 0; it < (1ll << 22); ++it) {
+    for (long long it = 0; it < (1ll << 18); ++it) {          // about a second
         int expected = 1;
         if (__hip_atomic_compare_exchange_strong(flag, &expected, 0, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
         __builtin_amdgcn_s_sleep(8);
@@ -3968,7 +3970,10 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
     hipEvent_t swept = nullptr, ready_deferred = nullptr;
     static const bool sweep_first = getenv("CS3_SWEEP_FIRST") && getenv("CS3_SWEEP_FIRST")[0] == '1';   // the round-1 capture order
     // hand-overs to the side queue through memory words instead of graph dependencies (k_flag_wait), pipelined root only
-    static const bool flag_env = !(getenv("CS3_FLAG_SYNC") && getenv("CS3_FLAG_SYNC")[0] == '0');
+    // OFF by default (CS3_FLAG_SYNC=1: 0.645 -> 0.63 ms per step on config 3): the waiting kernel needs the two queues to
+    // run at the same time, and a tool that serialises kernels (rocprofv3 --pmc, a debugger) leaves it alone on the device
+    // until it gives up -- the step then fails with an error instead of running a second slower
+    static const bool flag_env = getenv("CS3_FLAG_SYNC") && getenv("CS3_FLAG_SYNC")[0] == '1';
     const bool flags = flag_env && rootf && !sweep_first && nlevels >= 3;
     int *flag_ready = D.status + 1, *flag_home = D.status + 2;
     // the side branch forks after the first level and is captured after the second: captured first it would take the

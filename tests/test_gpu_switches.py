@@ -23,7 +23,7 @@ SETTINGS = [
     {"CS3_PROMOTE_MAX": "0", "CS3_RIDE_MAX": "0"},
     {"CS3_PROMOTE_MAX": "100000", "CS3_RIDE_MAX": "100000"},      # every small front beside a workgroup group joins it
     {"CS3_LDS_GRID": "0", "CS3_WG_MIN_BATCH": "100000"},            # fronts of order 33..64 through the four-wave shared elimination
-    {"CS3_FLAG_SYNC": "0"},                                         # fused step: graph dependencies instead of the memory-word hand-over
+    {"CS3_FLAG_SYNC": "1"},                                         # fused step: memory-word hand-over to the side queue instead of graph dependencies
 ]
 
 

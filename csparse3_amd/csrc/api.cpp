@@ -716,6 +716,12 @@ int cs3_import_factor_dev(cs3_handle h, const double *src_dev, void *stream)
     return CS3_OK;
 }
 
+int cs3_debug_poison_lds(void *stream)
+{
+    CS3_HIP(launch_poison_lds((hipStream_t) stream));
+    return CS3_OK;
+}
+
 int cs3_debug_schedule(cs3_handle h, int32_t *sched, int32_t *front_r, int32_t *front_w)
 {
     int rc = guard(h); if (rc) return rc;

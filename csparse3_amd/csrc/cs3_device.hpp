@@ -110,6 +110,7 @@ struct ForkJoin {
 };
 
 hipError_t prepare_kernels();
+hipError_t launch_poison_lds(hipStream_t st);     // diagnostics: NaN patterns into every CU's LDS
 hipError_t launch_diag_inverses(const DeviceFactor &D, hipStream_t st);
 bool permutation_can_fuse(const DeviceFactor &D, int nrhs);   // once after a factorisation, before a many-RHS sweep
 bool big_group_in_one_workgroup(int kind, long long batch, const LaunchGroup &g);

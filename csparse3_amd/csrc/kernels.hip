@@ -3436,6 +3436,26 @@ static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g
     return hipSuccess;
 }
 
+// Diagnostics: fill the LDS of every CU with NaN bit patterns (the LDS is not cleared between kernels), so that a kernel
+// which multiplies a masked-to-zero operand by an LDS word nobody wrote shows up as NaN in the parity tests.
+__global__ void __launch_bounds__(256) k_poison_lds(int words)
+{
+    extern __shared__ __attribute__((aligned(16))) double pz[];
+    for (int i = threadIdx.x; i < words; i += 256) pz[i] = __longlong_as_double(0x7ff8dead0000beefll);
+    __syncthreads();
+    if (pz[(threadIdx.x * 97) % words] == 0.0) pz[0] = 1.0;      // (keeps the stores)
+}
+
+hipError_t launch_poison_lds(hipStream_t st)
+{
+    const int bytes = 160 * 1024;
+    hipError_t e = hipFuncSetAttribute((const void *) k_poison_lds, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_poison_lds, dim3(1024), dim3(256), bytes, st, bytes / 8);      // four rounds over 256 CUs
+    CS3_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
 hipError_t prepare_kernels()
 {
     // the largest LDS-resident class needs more than the default 64 KiB of dynamic LDS

@@ -167,6 +167,9 @@ int cs3_import_factor_dev(cs3_handle h, const double *src_dev, void *stream);
  * stored) relative to its start; out[nsuper][8] in schedule order.  Not part
  * of the reference-facing surface. */
 int cs3_debug_front_stamps(cs3_handle h, int64_t *out);
+/* Fills the LDS of every CU with NaN bit patterns (the LDS keeps its contents between kernels): the parity tests call it
+ * before the numeric entry points so that a product of a masked zero and an unwritten LDS word cannot hide. */
+int cs3_debug_poison_lds(void *stream);
 /* Factorisation schedule: supernode id, front order r and width w per schedule slot. */
 int cs3_debug_schedule(cs3_handle h, int32_t *sched, int32_t *front_r, int32_t *front_w);
 

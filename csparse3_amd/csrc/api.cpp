@@ -94,7 +94,9 @@ void release_device(cs3_handle h)
     if (h->cap_stream) { (void) hipStreamDestroy(h->cap_stream); h->cap_stream = nullptr; }
     h->fj.destroy();
     void **ptrs[] = {(void **) &D.fdesc, (void **) &D.st_idx, (void **) &D.asm_src, (void **) &D.asm_tgt, (void **) &D.long_src,
-                     (void **) &D.sdesc, (void **) &D.fasm_src, (void **) &D.fasm_tgt, (void **) &D.flong_src, (void **) &D.rl_pairs,
+                     (void **) &D.sdesc, (void **) &D.sdesc1, (void **) &D.sub_tasks, (void **) &D.sub_fronts, (void **) &D.sub_lvl,
+                     (void **) &D.sub_rel, (void **) &D.sub_st, (void **) &D.sub_child, (void **) &D.sub_a_tgt, (void **) &D.sub_a_src,
+                     (void **) &D.axf, (void **) &D.fasm_src, (void **) &D.fasm_tgt, (void **) &D.flong_src, (void **) &D.rl_pairs,
                      (void **) &D.sl_src,                     (void **) &D.q, (void **) &D.ila_pairs, (void **) &D.inv_tasks, (void **) &D.dinv, (void **) &D.gv,
                      (void **) &D.ax, (void **) &D.pool, (void **) &D.dbuf, (void **) &D.tbuf, (void **) &D.bigv,
                      (void **) &D.cv, (void **) &D.xp, (void **) &D.status, (void **) &h->d_lmap, (void **) &h->d_umap,
@@ -104,6 +106,23 @@ void release_device(cs3_handle h)
     for (void **p : ptrs) if (*p) { (void) hipFree(*p); *p = nullptr; }
     D.nrhs_cap = 0;
     h->on_device = false;
+}
+
+SolveDesc solve_desc_of(const Symbolic &S, i32 s)
+{
+    SolveDesc f{};
+    f.lpan = S.lpan_off[s]; f.upan = S.upan_off[s]; f.cv = S.cv_off[s]; f.st = S.st_ptr[s];
+    f.fasm_begin = S.fasm_ptr[s]; f.fasm_count = (int) (S.fasm_ptr[s + 1] - S.fasm_ptr[s]);
+    f.bv = S.bv_off[s];
+    f.gv = S.gv_off[s]; f.dinv = S.dinv_off[s];
+    f.rl_begin = S.rl_ptr[s]; f.rl_count = (int) (S.rl_ptr[s + 1] - S.rl_ptr[s]);
+    if (S.sn_class[s] != FC_IL && !S.sn_il_panels[s]) { f.rl_begin = S.sl_ptr[s]; f.rl_count = S.sl_rounds[s]; }   // not a lane = matrix sweep
+    f.c0 = S.sn_ptr[s];
+    f.r = (int) (S.st_ptr[s + 1] - S.st_ptr[s]);
+    f.w = S.sn_ptr[s + 1] - S.sn_ptr[s];
+    f.u_sk = S.u_sk[s]; f.u_sj = S.u_sj[s];
+    f.parent = S.sn_parent[s];
+    return f;
 }
 
 int ensure_device_impl(cs3_handle h);
@@ -126,6 +145,7 @@ int ensure_device_impl(cs3_handle h)
         return CS3_ERR_HIP;
     }
     CS3_HIP(prepare_kernels());
+    CS3_HIP(prepare_forest_kernels());
     const Symbolic &S = h->S;
     DeviceFactor &D = h->D;
     D.kind = S.kind; D.n = S.n; D.nnz_a = S.nnzA; D.batch = h->batch;
@@ -154,22 +174,26 @@ int ensure_device_impl(cs3_handle h)
     }
     D.dbuf_size = dbuf_size;
     std::vector<SolveDesc> sdesc(S.nsuper);
-    for (i32 t = 0; t < S.nsuper; ++t) {
-        const i32 s = S.ssched[t];
-        SolveDesc &f = sdesc[t];
-        f.lpan = S.lpan_off[s]; f.upan = S.upan_off[s]; f.cv = S.cv_off[s]; f.st = S.st_ptr[s];
-        f.fasm_begin = S.fasm_ptr[s]; f.fasm_count = (int) (S.fasm_ptr[s + 1] - S.fasm_ptr[s]);
-        f.bv = S.bv_off[s];
-        f.gv = S.gv_off[s]; f.dinv = S.dinv_off[s];
-        f.rl_begin = S.rl_ptr[s]; f.rl_count = (int) (S.rl_ptr[s + 1] - S.rl_ptr[s]);
-        if (S.sn_class[s] != FC_IL && !S.sn_il_panels[s]) { f.rl_begin = S.sl_ptr[s]; f.rl_count = S.sl_rounds[s]; }   // not a lane = matrix sweep
-        f.c0 = S.sn_ptr[s];
-        f.r = (int) (S.st_ptr[s + 1] - S.st_ptr[s]);
-        f.w = S.sn_ptr[s + 1] - S.sn_ptr[s];
-        f.u_sk = S.u_sk[s]; f.u_sj = S.u_sj[s];
-        f.parent = S.sn_parent[s];
-    }
+    for (i32 t = 0; t < S.nsuper; ++t) sdesc[t] = solve_desc_of(S, S.ssched[t]);
     int rc;
+    // the bottom forest and the sweep schedule of one right-hand side that goes with it
+    D.sub_tiers = S.sub_tiers;
+    D.n_sub_a = (long long) S.sub_a_tgt.size();
+    D.sd_active = nullptr; D.fwd_in_factor = false;
+    if (!S.sub_tiers.empty()) {
+        std::vector<SolveDesc> sdesc1(S.nsuper);
+        for (i32 t = 0; t < S.nsuper; ++t) sdesc1[t] = solve_desc_of(S, S.ssched1[t]);
+        if ((rc = upload(&D.sdesc1, sdesc1))) return rc;
+        if ((rc = upload(&D.sub_tasks, S.sub_tasks))) return rc;
+        if ((rc = upload(&D.sub_fronts, S.sub_fronts))) return rc;
+        if ((rc = upload(&D.sub_lvl, S.sub_lvl))) return rc;
+        if ((rc = upload(&D.sub_rel, S.sub_rel))) return rc;
+        if ((rc = upload(&D.sub_st, S.sub_st))) return rc;
+        if ((rc = upload(&D.sub_child, S.sub_child))) return rc;
+        if ((rc = upload(&D.sub_a_tgt, S.sub_a_tgt))) return rc;
+        if ((rc = upload(&D.sub_a_src, S.sub_a_src))) return rc;
+        CS3_HIP(hipMalloc((void **) &D.axf, std::max<size_t>(1, (size_t) (D.batch * D.n_sub_a)) * sizeof(double)));
+    }
     if ((rc = upload(&D.sdesc, sdesc))) return rc;
     if ((rc = upload(&D.fasm_src, S.fasm_src))) return rc;
     if ((rc = upload(&D.fasm_tgt, S.fasm_tgt))) return rc;
@@ -247,9 +271,19 @@ int capture(cs3_handle h, hipGraphExec_t *exec, Body body)
     return CS3_OK;
 }
 
+// One right-hand side on a handle with a bottom forest: the sweeps follow the factor schedule (tiers, then the levels
+// above them) with their own descriptor array.  Sets what the launchers read; returns the launch groups to pass.
+const std::vector<LaunchGroup> &select_sweep_schedule(cs3_handle h, int nrhs)
+{
+    const bool forest = nrhs == 1 && !h->S.sub_tiers.empty();
+    h->D.sd_active = forest ? h->D.sdesc1 : nullptr;
+    return forest ? h->S.sgroups1 : h->S.sgroups;
+}
+
 int run_factor(cs3_handle h, const double *ax_dev, double tol, hipStream_t st)
 {
     DeviceFactor &D = h->D;
+    D.fwd_in_factor = false;
     const double inv_tol = (tol > 0.0) ? 1.0 / tol : HUGE_VAL;
     CS3_HIP(launch_prologue(D, ax_dev, nullptr, 0, st));        // status 0x7f7f7f7f = clean, zeros, values
     if (h->use_graph) {
@@ -307,6 +341,8 @@ int run_solve(cs3_handle h, double *x_dev, long long k, int mode, hipStream_t st
     DeviceFactor &D = h->D;
     const int nrhs = (int) k;
     D.inverses_in_sweep = false;
+    D.fwd_in_factor = false;
+    const std::vector<LaunchGroup> &sg = select_sweep_schedule(h, nrhs);
     if (nrhs >= 16 && D.n_inv_tasks > 0 && !h->inverses_valid) {      // many right-hand sides: GEMM sweeps need the inverted blocks
         CS3_HIP(launch_diag_inverses(D, st));
         h->inverses_valid = true;
@@ -327,17 +363,17 @@ int run_solve(cs3_handle h, double *x_dev, long long k, int mode, hipStream_t st
                 }
                 hipGraphExec_t exec = nullptr;
                 rc = capture(h, &exec, [&](hipStream_t cs) {
-                    hipError_t e = launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, true, cs, h->fj);
+                    hipError_t e = launch_solve_levels(D, sg, D.xp, nrhs, true, cs, h->fj);
                     if (e != hipSuccess) return e;
-                    return launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, false, cs, h->fj);
+                    return launch_solve_levels(D, sg, D.xp, nrhs, false, cs, h->fj);
                 });
                 if (rc) { D.xm = XMap(); return rc; }
                 it = h->solve_graphs_px.emplace(key, exec).first;
             }
             CS3_HIP(hipGraphLaunch(it->second, st));
         } else {
-            CS3_HIP(launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, true, st, h->fj));
-            CS3_HIP(launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, false, st, h->fj));
+            CS3_HIP(launch_solve_levels(D, sg, D.xp, nrhs, true, st, h->fj));
+            CS3_HIP(launch_solve_levels(D, sg, D.xp, nrhs, false, st, h->fj));
         }
         D.xm = XMap();
     } else if (mode == 0) {
@@ -347,21 +383,21 @@ int run_solve(cs3_handle h, double *x_dev, long long k, int mode, hipStream_t st
             if (it == h->solve_graphs.end()) {
                 hipGraphExec_t exec = nullptr;
                 rc = capture(h, &exec, [&](hipStream_t cs) {
-                    hipError_t e = launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, true, cs, h->fj);
+                    hipError_t e = launch_solve_levels(D, sg, D.xp, nrhs, true, cs, h->fj);
                     if (e != hipSuccess) return e;
-                    return launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, false, cs, h->fj);
+                    return launch_solve_levels(D, sg, D.xp, nrhs, false, cs, h->fj);
                 });
                 if (rc) return rc;
                 it = h->solve_graphs.emplace(nrhs, exec).first;
             }
             CS3_HIP(hipGraphLaunch(it->second, st));
         } else {
-            CS3_HIP(launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, true, st, h->fj));
-            CS3_HIP(launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, false, st, h->fj));
+            CS3_HIP(launch_solve_levels(D, sg, D.xp, nrhs, true, st, h->fj));
+            CS3_HIP(launch_solve_levels(D, sg, D.xp, nrhs, false, st, h->fj));
         }
         CS3_HIP(launch_permute(D, D.xp, x_dev, nrhs, true, st));
     } else {
-        CS3_HIP(launch_solve_levels(D, h->S.sgroups, x_dev, nrhs, mode == 1, st, h->fj));
+        CS3_HIP(launch_solve_levels(D, sg, x_dev, nrhs, mode == 1, st, h->fj));
     }
     return CS3_OK;
 }
@@ -375,6 +411,8 @@ int run_factor_solve(cs3_handle h, const double *ax_dev, const double *b_dev, do
     DeviceFactor &D = h->D;
     const int nrhs = (int) k;
     const double inv_tol = (tol > 0.0) ? 1.0 / tol : HUGE_VAL;
+    const std::vector<LaunchGroup> &sg = select_sweep_schedule(h, nrhs);
+    D.fwd_in_factor = nrhs == 1 && !h->S.sub_tiers.empty();   // the tiers' factor launches carry their forward sweep
     D.inverses_in_sweep = true;                                // captured with the graph: the forward sweep inverts group by group
     CS3_HIP(launch_prologue(D, ax_dev, b_dev, nrhs, st));      // right-hand sides are read from b_dev, the solution goes to x_dev
     if (h->use_graph) {
@@ -398,9 +436,9 @@ int run_factor_solve(cs3_handle h, const double *ax_dev, const double *b_dev, do
                 }
                 hipGraphExec_t exec = nullptr;
                 rc = capture(h, &exec, [&](hipStream_t cs) {
-                    hipError_t e = launch_factor_with_forward(D, h->S.groups, h->S.sgroups, inv_tol, D.xp, nrhs, cs, h->fj);
+                    hipError_t e = launch_factor_with_forward(D, h->S.groups, sg, inv_tol, D.xp, nrhs, cs, h->fj);
                     if (e != hipSuccess) return e;
-                    if ((e = launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, false, cs, h->fj)) != hipSuccess) return e;
+                    if ((e = launch_solve_levels(D, sg, D.xp, nrhs, false, cs, h->fj)) != hipSuccess) return e;
                     return launch_permute(D, D.xp, x_dev, nrhs, true, cs);
                 });
                 if (rc) return rc;
@@ -408,6 +446,7 @@ int run_factor_solve(cs3_handle h, const double *ax_dev, const double *b_dev, do
             }
             CS3_HIP(hipGraphLaunch(px->second, st));
             D.inverses_in_sweep = false;
+    D.fwd_in_factor = false;
             h->factored = true;
             h->inverses_valid = nrhs >= 16;
             return CS3_OK;
@@ -416,20 +455,21 @@ int run_factor_solve(cs3_handle h, const double *ax_dev, const double *b_dev, do
         if (it == h->fused_graphs.end()) {
             hipGraphExec_t exec = nullptr;
             rc = capture(h, &exec, [&](hipStream_t cs) {
-                hipError_t e = launch_factor_with_forward(D, h->S.groups, h->S.sgroups, inv_tol, D.xp, nrhs, cs, h->fj);
+                hipError_t e = launch_factor_with_forward(D, h->S.groups, sg, inv_tol, D.xp, nrhs, cs, h->fj);
                 if (e != hipSuccess) return e;
-                return launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, false, cs, h->fj);
+                return launch_solve_levels(D, sg, D.xp, nrhs, false, cs, h->fj);
             });
             if (rc) return rc;
             it = h->fused_graphs.emplace(nrhs, exec).first;
         }
         CS3_HIP(hipGraphLaunch(it->second, st));
     } else {
-        CS3_HIP(launch_factor_with_forward(D, h->S.groups, h->S.sgroups, inv_tol, D.xp, nrhs, st, h->fj));
-        CS3_HIP(launch_solve_levels(D, h->S.sgroups, D.xp, nrhs, false, st, h->fj));
+        CS3_HIP(launch_factor_with_forward(D, h->S.groups, sg, inv_tol, D.xp, nrhs, st, h->fj));
+        CS3_HIP(launch_solve_levels(D, sg, D.xp, nrhs, false, st, h->fj));
     }
     CS3_HIP(launch_permute(D, D.xp, x_dev, nrhs, true, st));
     D.inverses_in_sweep = false;
+    D.fwd_in_factor = false;
     h->factored = true;
     h->inverses_valid = nrhs >= 16;                            // a many-RHS fused call leaves them current
     return CS3_OK;
@@ -733,6 +773,26 @@ int cs3_debug_schedule(cs3_handle h, int32_t *sched, int32_t *front_r, int32_t *
         if (front_w) front_w[t] = S.sn_ptr[s + 1] - S.sn_ptr[s];
     }
     return CS3_OK;
+}
+
+int64_t cs3_debug_forest(cs3_handle h, int32_t *supernode, int32_t *task, int32_t *level, int32_t *tier)
+{
+    if (guard(h)) return -1;
+    const Symbolic &S = h->S;
+    for (size_t ti = 0; ti < S.sub_tiers.size(); ++ti) {
+        const SubTier &T = S.sub_tiers[ti];
+        for (i32 k = T.task0; k < T.task0 + T.ntasks; ++k) {
+            const SubTask &K = S.sub_tasks[k];
+            for (i32 l = 0; l < K.nlevels; ++l)
+                for (i32 f = K.front0 + S.sub_lvl[K.lvl0 + 2 * l]; f < K.front0 + S.sub_lvl[K.lvl0 + 2 * l + 2]; ++f) {
+                    if (supernode) supernode[f] = S.sub_sn[f];
+                    if (task) task[f] = k;
+                    if (level) level[f] = l;
+                    if (tier) tier[f] = (i32) ti;
+                }
+        }
+    }
+    return (int64_t) S.sub_sn.size();
 }
 
 int cs3_debug_front_stamps(cs3_handle h, int64_t *out)

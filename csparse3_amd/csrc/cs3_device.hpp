@@ -59,6 +59,19 @@ struct DeviceFactor {
     int *st_idx = nullptr;        // row structures (backward sweep: rows of the ancestors)
     int *asm_src = nullptr, *asm_tgt = nullptr, *long_src = nullptr;
     SolveDesc *sdesc = nullptr;
+    // one right-hand side with a bottom forest: descriptors in the order of Symbolic::ssched1; sd_active is what the sweep
+    // launchers hand to the kernels (set by the caller together with the launch groups it passes: sdesc or sdesc1)
+    SolveDesc *sdesc1 = nullptr;
+    const SolveDesc *sd_active = nullptr;
+    const SolveDesc *sd() const { return sd_active ? sd_active : sdesc; }
+    // bottom forest (cs3_internal.hpp): tasks, their fronts and lists; axf = the values of A in the order of sub_a_tgt
+    std::vector<SubTier> sub_tiers;
+    SubTask *sub_tasks = nullptr;
+    SubFront *sub_fronts = nullptr;
+    int *sub_lvl = nullptr, *sub_rel = nullptr, *sub_st = nullptr, *sub_child = nullptr, *sub_a_tgt = nullptr, *sub_a_src = nullptr;
+    double *axf = nullptr;        // [batch][n_sub_a]
+    long long n_sub_a = 0;
+    bool fwd_in_factor = false;   // the tiers' factor launches carry the forward sweep of their fronts (fused factor + solve, one right-hand side)
     int *fasm_src = nullptr, *fasm_tgt = nullptr, *flong_src = nullptr;
     int *rl_pairs = nullptr, *sl_src = nullptr;
     int *q = nullptr;             // [n] pivot order
@@ -125,6 +138,10 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
                                       hipStream_t st, ForkJoin &fj);
 // status word, big-front zeros, copy of the caller's values and (x_src != null) the permuted right-hand sides, one launch
 hipError_t launch_prologue(const DeviceFactor &D, const double *ax_src, const double *x_src, int nrhs, hipStream_t st);
+// forest.hip: one tier of the bottom forest = one launch, one workgroup per task
+hipError_t prepare_forest_kernels();
+hipError_t launch_sub_factor(const DeviceFactor &D, int tier, bool with_forward, double inv_tol, hipStream_t st);
+hipError_t launch_sub_sweep(const DeviceFactor &D, int tier, double *X, bool forward, hipStream_t st);
 hipError_t launch_permute(const DeviceFactor &D, const double *src, double *dst, int nrhs, bool scatter,
                           hipStream_t st);
 hipError_t launch_extract(const double *vals, const double *vals_il, long long il_len, const long long *map, double *out,

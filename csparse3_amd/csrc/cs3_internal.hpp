@@ -31,7 +31,8 @@ void cholesky_counts(i64 n, const i32 *Ap, const i32 *Ai, const i32 *parent,
 
 // Size classes of fronts; each class is one kernel configuration.
 // FC_IL: small fronts of a large batch, stored matrix-interleaved and processed lane = matrix (k_front_il).
-enum FrontClass : int { FC_R16 = 0, FC_R32 = 1, FC_R64 = 2, FC_LDS = 3, FC_BIG = 4, FC_IL = 5, FC_COUNT = 6 };
+// FC_SUB: fronts of the bottom forest -- whole subtrees of small fronts walked by ONE workgroup in one launch (k_sub_*).
+enum FrontClass : int { FC_R16 = 0, FC_R32 = 1, FC_R64 = 2, FC_LDS = 3, FC_BIG = 4, FC_IL = 5, FC_SUB = 6, FC_COUNT = 7 };
 
 // Solve kernels by front shape.  SK_SMALL and SK_WAVE share the one-wave-per-front kernels for few
 // right-hand sides (adjacent in the schedule, launched as one group); with many right-hand sides
@@ -41,7 +42,8 @@ enum SolveKind : int {
     SK_WAVE = 1,       // r <= 128, w <= 64
     SK_BLOCK = 2,      // one workgroup per front
     SK_BIG = 3,        // w > 64, r > 136: one launch per 64-column chunk, many workgroups
-    SK_IL = 4          // matrix-interleaved small fronts of a large batch: lane = matrix (k_fwd_il / k_bwd_il)
+    SK_IL = 4,         // matrix-interleaved small fronts of a large batch: lane = matrix (k_fwd_il / k_bwd_il)
+    SK_SUB = 5         // a tier of the bottom forest: one workgroup per task (k_sub_fwd / k_sub_bwd), one right-hand side
 };
 
 struct LaunchGroup {          // fronts of one level that share a kernel configuration
@@ -52,7 +54,48 @@ struct LaunchGroup {          // fronts of one level that share a kernel configu
     i32 max_w;                // widest supernode in the group (block steps of the big path)
     i64 max_asm;              // longest assembly list in the group
     i32 n16 = 0;              // solve groups: leading fronts of order <= 16 (sorted first: a leaner kernel instance takes them)
-    i32 need = 0;             // factor groups: lowest level that holds a parent of one of these fronts (INT32_MAX: roots only)
+};
+
+// ---- the bottom forest (symbolic.cpp, step 6b) ------------------------------------------------------------------
+// A dependent launch costs microseconds whatever it holds, and the bottom of the tree is thousands of tiny fronts on a
+// dozen levels.  Subtrees whose fronts all have order <= SUB_RMAX are cut out of the level schedule and handed to ONE
+// workgroup each (a TASK; small subtrees are packed together): the workgroup walks its fronts level by level with
+// block barriers in between, one wave per front, and the contribution blocks (and vectors) of its fronts stay in
+// its LDS.  What is left above a tier of tasks is searched again (tier 1, 2, ...: their tasks read the blocks of
+// the tier below from the pool), and what is left above the last tier runs level by level as before.
+constexpr i32 SUB_RMAX = 32;                  // one wave holds a front of this order in registers (lane = row)
+
+// One front of a task as the k_sub_* kernels read it (staged in LDS for the whole task).  16 ints.
+struct SubFront {
+    i32 lpan, upan;               // pool offsets of the panels
+    i32 cb;                       // contribution block: >= 0 pool offset (compact nb x nb; the parent is outside the task),
+                                  //   < 0: ~offset (doubles) in the task's LDS arena, nb x (nb + 1): the last column is the
+                                  //   contribution vector of the fused forward sweep
+    i32 cv;                       // contribution vector in the global pool (parent outside the task, and every stand-alone sweep)
+    i32 c0, r, w;
+    i32 a_begin, a_count;         // entries of A: sub_a_tgt / the forest-ordered copy of the values
+    i32 child_begin, child_count; // sub_child (4 ints per child): update rows nbc | own task << 16, row map, block, vector
+    i32 rel;                      // sub_rel + rel: where my update rows sit in the parent's structure (nb entries)
+    i32 st;                       // st_idx + st: my row structure (backward sweep: the ancestors' rows)
+    i32 u_sj;                     // U(k, j) = pool[upan + k + (j - w) u_sj]
+    i32 parent;                   // position of the parent's SubFront, -1: the parent is not a forest front / none
+    i32 arena;                    // offset (doubles) of my contribution VECTOR in the LDS arena of the stand-alone sweeps
+};
+
+struct SubTask {                  // one workgroup
+    i32 front0, nfronts;          // its SubFronts, sorted by local level
+    i32 lvl0, nlevels;            // sub_lvl[lvl0 + 2 l]: first front (relative to front0) of local level l, [.. + 1]: how many of its
+                                  //   leading fronts are shared by four waves; sub_lvl[lvl0 + 2 nlevels] = nfronts
+    i32 rel0, nrel;               // its slice of sub_rel
+    i32 child0, nchild;           // its slice of sub_child, in children (4 ints each)
+};
+
+struct SubTier {                  // one launch
+    i32 task0 = 0, ntasks = 0;
+    i32 max_fronts = 0, max_levels = 0, max_rel = 0, max_child = 0;   // LDS staging sizes
+    i32 max_arena = 0;            // doubles: contribution blocks of a task that stay in LDS
+    i32 max_varena = 0;           // doubles: contribution vectors (stand-alone sweeps)
+    i32 max_r = 0;
 };
 
 struct Symbolic {
@@ -119,6 +162,18 @@ struct Symbolic {
     i64 gv_size = 0, dinv_size = 0;
     std::vector<i32> inv_tasks;
     std::vector<LaunchGroup> sgroups;
+    // bottom forest (empty when off): sn_tier[s] = tier of supernode s, -1 above the forest
+    std::vector<i32> sn_tier, sn_tlevel;      // sn_tlevel: tier for forest fronts, ntiers + height above the forest otherwise
+    std::vector<SubTier> sub_tiers;
+    std::vector<SubTask> sub_tasks;
+    std::vector<SubFront> sub_fronts;
+    std::vector<i32> sub_sn;                  // supernode of each SubFront
+    std::vector<i32> sub_lvl, sub_rel, sub_child;
+    std::vector<i32> sub_st;                  // parallel to sub_rel: the global row behind each update row (backward sweep)
+    std::vector<i32> sub_a_tgt, sub_a_src;    // A entries of the forest fronts: target in the LDS image, entry of Ax
+    // one right-hand side with a forest: the sweeps follow the factor schedule (tiers, then the levels above them)
+    std::vector<i32> ssched1;
+    std::vector<LaunchGroup> sgroups1;
     // schedule
     i32 nlevels = 0;
     std::vector<i32> sched;                   // supernode ids grouped by (level, class)

@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "cs3_device.hpp"
+#include "cs3_devfn.hpp"
 
 namespace cs3 {
 
@@ -36,42 +37,6 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // (pool offset, or ~index into Ax) and the wave sums each run with a fixed
 // shuffle tree: every front entry is written exactly once, by one lane, and
 // the summation order never changes from run to run.
-// Load-then-select: a predicated `cond ? p[i] : 0` makes hipcc branch around the
-// load and wait for it alone; loading from a safe address keeps loads in flight.
-__device__ __forceinline__ double load_if(const double *__restrict__ p, long long off, bool ok)
-{
-    const double v = p[ok ? off : 0];
-    return ok ? v : 0.0;
-}
-
-// 1 / x on the critical path of every pivot: v_rcp_f64 and two Newton steps (about 1 ulp) instead of the
-// IEEE division sequence (div_scale / fmas / fixup, three times the dependent instructions).  A zero
-// or non-finite pivot still yields inf / nan, which the pivot checks reject.
-__device__ __forceinline__ double fast_rcp(double x)
-{
-    double y = __builtin_amdgcn_rcp(x);
-    y = fma(fma(-x, y, 1.0), y, y);
-    y = fma(fma(-x, y, 1.0), y, y);
-    return y;
-}
-
-// 1 / diagonal entry `i` of an r-row panel: the sweeps multiply by it (one division per lane instead
-// of one per pivot step executed by the whole wave)
-__device__ __forceinline__ double recip_diag(const double *__restrict__ L, long long i, long long r, bool ok)
-{
-    const double dg = L[ok ? i * (r + 1) : 0];
-    return 1.0 / (ok ? dg : 1.0);
-}
-
-__device__ __forceinline__ int bcast_lane_i(int x, int k) { return __builtin_amdgcn_readlane(x, k); }   // k wave-uniform
-
-__device__ __forceinline__ double bcast_lane(double x, int k)     // k wave-uniform
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(x), k);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), k);
-    return __hiloint2double(hi, lo);
-}
-
 // Interleaved block: entry `off` (< il.len) of matrix m is  il_lane_base(il, m)[off * 64].
 __device__ __forceinline__ double *il_lane_base(const IlView &il, long long m)
 {
@@ -187,11 +152,6 @@ __device__ __forceinline__ void gather_front_vec(long long asm_begin, int nchunk
             for (int q = 0; q < NV; ++q) store(tt, q, v[q]);
         }
     }
-}
-
-__device__ __forceinline__ void flag_column(int *status, int col)
-{
-    atomicMin(status, col);
 }
 
 // ------------------------------------------------- front resident in LDS --
@@ -3106,11 +3066,14 @@ k_permute_rows(const double *__restrict__ src, double *__restrict__ dst, const i
 __global__ void __launch_bounds__(256)
 k_prologue(int *status, double *__restrict__ pool, long long big_begin, long long nzero, long long pool_stride,
            long long batch, const double *__restrict__ ax_src, double *__restrict__ ax_dst, long long nax,
-           const double *__restrict__ x_src, double *__restrict__ xp, const int *__restrict__ q, long long n, int nrhs)
+           const double *__restrict__ x_src, double *__restrict__ xp, const int *__restrict__ q, long long n, int nrhs,
+           const int *__restrict__ f_src, double *__restrict__ axf, long long nf, long long nnz_a)
 {
     const long long t0 = (long long) blockIdx.x * blockDim.x + threadIdx.x, stride = (long long) gridDim.x * blockDim.x;
     if (t0 == 0) { status[0] = 0x7f7f7f7f; status[1] = 0; status[2] = 0; }      // ... and the two hand-over words of the fused step
     const long long z_all = nzero * batch, x_all = x_src ? n * nrhs * batch : 0;
+    // the values of the bottom forest's fronts in THEIR order (forest.hip reads them without an index indirection)
+    for (long long t = t0; t < nf * batch; t += stride) axf[t] = ax_src[(t / nf) * nnz_a + f_src[t % nf]];
     for (long long t = t0; t < z_all + nax + x_all; t += stride) {
         if (t < z_all) {
             pool[(t / nzero) * pool_stride + big_begin + t % nzero] = 0.0;
@@ -3374,6 +3337,7 @@ template <int KIND>
 static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g, double inv_tol, hipStream_t st)
 {
     const unsigned batch = (unsigned) D.batch;
+    if (g.cls == FC_SUB) return launch_sub_factor(D, g.first, D.fwd_in_factor, inv_tol, st);     // a tier of the bottom forest
     if (big_group_in_one_workgroup(KIND, D.batch, g)) {
         if (wg_nb() == 16)
             hipLaunchKernelGGL((k_front_wg<KIND, 16>), dim3((unsigned) g.count, batch), dim3(512), wg_lds_bytes(KIND, g), st, D.fdesc,
@@ -3597,7 +3561,7 @@ static BigSweepPlan big_sweep_plan(const DeviceFactor &D, const LaunchGroup &g, 
 static hipError_t launch_fwd_big_pre(const DeviceFactor &D, const LaunchGroup &g, double *X, int nrhs, hipStream_t st)
 {
     const BigSweepPlan pl = big_sweep_plan(D, g, nrhs);
-    hipLaunchKernelGGL(k_fwd_big_gather, dim3(1, pl.by, g.count), dim3(256), 0, st, D.sdesc, g.first, D.fasm_src,
+    hipLaunchKernelGGL(k_fwd_big_gather, dim3(1, pl.by, g.count), dim3(256), 0, st, D.sd(), g.first, D.fasm_src,
                        D.fasm_tgt, D.flong_src, D.cv, X, D.bigv, nrhs, D.cv_size * (long long) nrhs, D.n * (long long) nrhs, D.bv_size);
     CS3_LAUNCH_CHECK();
     return hipSuccess;
@@ -3609,13 +3573,13 @@ static hipError_t launch_fwd_big_chunk(const DeviceFactor &D, const LaunchGroup 
     const BigSweepPlan pl = big_sweep_plan(D, g, nrhs);
     const long long xs = D.n * (long long) nrhs, cvs = D.cv_size * (long long) nrhs;
     if (pl.wide)
-        hipLaunchKernelGGL((k_fwd_big_step<KIND, BIG_CW>), dim3(pl.slices, pl.by, g.count), dim3(256), 0, st, D.sdesc,
+        hipLaunchKernelGGL((k_fwd_big_step<KIND, BIG_CW>), dim3(pl.slices, pl.by, g.count), dim3(256), 0, st, D.sd(),
                            g.first, c * pl.cw, D.pool_pm, D.cv, X, D.bigv, nrhs, D.pm_stride, cvs, xs, D.bv_size);
     else if (pl.multi)
-        hipLaunchKernelGGL((k_fwd_big_step_multi<KIND>), dim3(pl.slices, pl.by_multi, g.count), dim3(256), 0, st, D.sdesc,
+        hipLaunchKernelGGL((k_fwd_big_step_multi<KIND>), dim3(pl.slices, pl.by_multi, g.count), dim3(256), 0, st, D.sd(),
                            g.first, c * pl.cw, D.pool_pm, D.cv, X, D.bigv, nrhs, D.pm_stride, cvs, xs, D.bv_size);
     else
-        hipLaunchKernelGGL((k_fwd_big_step<KIND, SOLVE_BW>), dim3(pl.slices, pl.by, g.count), dim3(256), 0, st, D.sdesc,
+        hipLaunchKernelGGL((k_fwd_big_step<KIND, SOLVE_BW>), dim3(pl.slices, pl.by, g.count), dim3(256), 0, st, D.sd(),
                            g.first, c * pl.cw, D.pool_pm, D.cv, X, D.bigv, nrhs, D.pm_stride, cvs, xs, D.bv_size);
     CS3_LAUNCH_CHECK();
     return hipSuccess;
@@ -3626,7 +3590,7 @@ static hipError_t launch_bwd_big_pre(const DeviceFactor &D, const LaunchGroup &g
 {
     const BigSweepPlan pl = big_sweep_plan(D, g, nrhs);
     const size_t lds = (size_t) std::max(1, g.max_r) * sizeof(double);
-    hipLaunchKernelGGL((k_bwd_big_init<KIND>), dim3(2, pl.by, g.count), dim3(256), lds, st, D.sdesc, g.first,
+    hipLaunchKernelGGL((k_bwd_big_init<KIND>), dim3(2, pl.by, g.count), dim3(256), lds, st, D.sd(), g.first,
                        D.st_idx, D.pool_pm, X, D.bigv, nrhs, D.pm_stride, D.n * (long long) nrhs, D.bv_size);
     CS3_LAUNCH_CHECK();
     return hipSuccess;
@@ -3638,13 +3602,13 @@ static hipError_t launch_bwd_big_chunk(const DeviceFactor &D, const LaunchGroup 
     const BigSweepPlan pl = big_sweep_plan(D, g, nrhs);
     const long long xs = D.n * (long long) nrhs;
     if (pl.wide)
-        hipLaunchKernelGGL((k_bwd_big_step<KIND, BIG_CW>), dim3(pl.slices, pl.by, g.count), dim3(256), 0, st, D.sdesc,
+        hipLaunchKernelGGL((k_bwd_big_step<KIND, BIG_CW>), dim3(pl.slices, pl.by, g.count), dim3(256), 0, st, D.sd(),
                            g.first, c, D.pool_pm, X, D.bigv, nrhs, D.pm_stride, xs, D.bv_size);
     else if (pl.multi)
-        hipLaunchKernelGGL((k_bwd_big_step_multi<KIND>), dim3(pl.slices, pl.by_multi, g.count), dim3(256), 0, st, D.sdesc,
+        hipLaunchKernelGGL((k_bwd_big_step_multi<KIND>), dim3(pl.slices, pl.by_multi, g.count), dim3(256), 0, st, D.sd(),
                            g.first, c, D.pool_pm, X, D.bigv, nrhs, D.pm_stride, xs, D.bv_size);
     else
-        hipLaunchKernelGGL((k_bwd_big_step<KIND, SOLVE_BW>), dim3(pl.slices, pl.by, g.count), dim3(256), 0, st, D.sdesc,
+        hipLaunchKernelGGL((k_bwd_big_step<KIND, SOLVE_BW>), dim3(pl.slices, pl.by, g.count), dim3(256), 0, st, D.sd(),
                            g.first, c, D.pool_pm, X, D.bigv, nrhs, D.pm_stride, xs, D.bv_size);
     CS3_LAUNCH_CHECK();
     return hipSuccess;
@@ -3705,21 +3669,21 @@ static hipError_t launch_gemm_group(const DeviceFactor &D, const LaunchGroup &g,
     const int nchunk = (g.max_w + GC - 1) / GC;
     const unsigned slices = (unsigned) std::max(1, (g.max_r + GC - 1) / GC);
     if (forward) {
-        hipLaunchKernelGGL(k_gemm_gather, dim3((unsigned) ((g.max_r + 15) / 16), tiles, g.count * batch), dim3(256), 0, st, D.sdesc,
+        hipLaunchKernelGGL(k_gemm_gather, dim3((unsigned) ((g.max_r + 15) / 16), tiles, g.count * batch), dim3(256), 0, st, D.sd(),
                            g.first, D.sl_src, D.cv, X, D.gv, nrhs, cvs, xs, gvs, D.xm, (int) batch);
         CS3_LAUNCH_CHECK();
         for (int c = 0; c < nchunk; ++c) {
-            hipLaunchKernelGGL((k_gemm_fwd<KIND>), dim3(slices, tiles, g.count * batch), dim3(256), GEMM_LDS, st, D.sdesc, g.first, c,
+            hipLaunchKernelGGL((k_gemm_fwd<KIND>), dim3(slices, tiles, g.count * batch), dim3(256), GEMM_LDS, st, D.sd(), g.first, c,
                                D.pool_pm, D.dinv, D.cv, X, D.gv, nrhs, D.pm_stride, D.dinv_size, cvs, xs, gvs, (int) batch);
             CS3_LAUNCH_CHECK();
         }
     } else {
-        hipLaunchKernelGGL((k_gemm_bwd_init<KIND>), dim3((unsigned) nchunk, tiles, g.count * batch), dim3(256), GEMM_LDS, st, D.sdesc,
+        hipLaunchKernelGGL((k_gemm_bwd_init<KIND>), dim3((unsigned) nchunk, tiles, g.count * batch), dim3(256), GEMM_LDS, st, D.sd(),
                            g.first, D.st_idx, D.pool_pm, X, D.gv, nrhs, D.pm_stride, xs, gvs, (int) batch);
         CS3_LAUNCH_CHECK();
         for (int c = 0; c < nchunk; ++c) {
             hipLaunchKernelGGL((k_gemm_bwd<KIND>), dim3((unsigned) std::max(1, nchunk), tiles, g.count * batch), dim3(256), GEMM_LDS, st,
-                               D.sdesc, g.first, c, D.pool_pm, D.dinv, X, D.gv, nrhs, D.pm_stride, D.dinv_size, xs, gvs, (int) batch, D.xm);
+                               D.sd(), g.first, c, D.pool_pm, D.dinv, X, D.gv, nrhs, D.pm_stride, D.dinv_size, xs, gvs, (int) batch, D.xm);
             CS3_LAUNCH_CHECK();
         }
     }
@@ -3733,10 +3697,10 @@ static void launch_rhs_sweep(const DeviceFactor &D, int first, int count, double
     const long long xs = D.n * (long long) nrhs, cvs = D.cv_size * (long long) nrhs;
     dim3 grid((unsigned) count, (unsigned) D.batch, (unsigned) ((nrhs + 63) / 64));
     if (forward)
-        hipLaunchKernelGGL((k_fwd_rhs<KIND, RMAX>), grid, dim3(64), 0, st, D.sdesc, first, D.sl_src, D.pool_pm, D.cv, X,
+        hipLaunchKernelGGL((k_fwd_rhs<KIND, RMAX>), grid, dim3(64), 0, st, D.sd(), first, D.sl_src, D.pool_pm, D.cv, X,
                            nrhs, D.pm_stride, cvs, xs, D.xm);
     else
-        hipLaunchKernelGGL((k_bwd_rhs<KIND, RMAX>), grid, dim3(64), 0, st, D.sdesc, first, D.st_idx, D.pool_pm, X,
+        hipLaunchKernelGGL((k_bwd_rhs<KIND, RMAX>), grid, dim3(64), 0, st, D.sd(), first, D.st_idx, D.pool_pm, X,
                            nrhs, D.pm_stride, xs, D.xm);
 }
 
@@ -3746,6 +3710,7 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
 {
     const long long xs = D.n * (long long) nrhs;
     const long long cvs = D.cv_size * (long long) nrhs;
+    if (g.cls == SK_SUB) return (nrhs == 1) ? launch_sub_sweep(D, g.first, X, forward, st) : hipErrorInvalidValue;
     static const bool use_gemm = !(getenv("CS3_NO_GEMM_SWEEPS") && getenv("CS3_NO_GEMM_SWEEPS")[0] == '1');
     if (use_gemm && nrhs >= RHS_LANES_MIN && (g.cls == SK_WAVE || g.cls == SK_BLOCK || g.cls == SK_BIG))
         return launch_gemm_group<KIND>(D, g, X, nrhs, forward, forward && D.inverses_in_sweep, st);
@@ -3757,19 +3722,19 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
         if (n16 > 0) {
             dim3 grid((unsigned) n16, (unsigned) D.ngroups);
             if (forward)
-                hipLaunchKernelGGL((k_fwd_il<KIND, 16>), grid, dim3(64), 0, st, D.sdesc, g.first, D.rl_pairs,
+                hipLaunchKernelGGL((k_fwd_il<KIND, 16>), grid, dim3(64), 0, st, D.sd(), g.first, D.rl_pairs,
                                    IlView{D.pool_il, D.il_len}, D.cv, X, nrhs, cvs, xs, (int) D.batch);
             else
-                hipLaunchKernelGGL((k_bwd_il<KIND, 16>), grid, dim3(64), 0, st, D.sdesc, g.first, D.st_idx,
+                hipLaunchKernelGGL((k_bwd_il<KIND, 16>), grid, dim3(64), 0, st, D.sd(), g.first, D.st_idx,
                                    IlView{D.pool_il, D.il_len}, X, nrhs, xs, (int) D.batch);
         }
         if (g.count > n16) {
             dim3 grid((unsigned) (g.count - n16), (unsigned) D.ngroups);
             if (forward)
-                hipLaunchKernelGGL((k_fwd_il<KIND, IL_RMAX>), grid, dim3(64), 0, st, D.sdesc, g.first + n16, D.rl_pairs,
+                hipLaunchKernelGGL((k_fwd_il<KIND, IL_RMAX>), grid, dim3(64), 0, st, D.sd(), g.first + n16, D.rl_pairs,
                                    IlView{D.pool_il, D.il_len}, D.cv, X, nrhs, cvs, xs, (int) D.batch);
             else
-                hipLaunchKernelGGL((k_bwd_il<KIND, IL_RMAX>), grid, dim3(64), 0, st, D.sdesc, g.first + n16, D.st_idx,
+                hipLaunchKernelGGL((k_bwd_il<KIND, IL_RMAX>), grid, dim3(64), 0, st, D.sd(), g.first + n16, D.st_idx,
                                    IlView{D.pool_il, D.il_len}, X, nrhs, xs, (int) D.batch);
         }
     } else if (g.cls == SK_SMALL && nrhs >= RHS_LANES_MIN) {
@@ -3789,19 +3754,19 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
         if (nrhs == 1) {
             dim3 grid((unsigned) ((g.count + 3) / 4), (unsigned) D.batch, 1);
             if (forward)
-                hipLaunchKernelGGL((k_fwd_wave<KIND, 1>), grid, dim3(256), 0, st, D.sdesc, g.first, g.count, D.fasm_src,
+                hipLaunchKernelGGL((k_fwd_wave<KIND, 1>), grid, dim3(256), 0, st, D.sd(), g.first, g.count, D.fasm_src,
                                    D.fasm_tgt, D.flong_src, D.pool_pm, D.cv, X, nrhs, D.pm_stride, cvs, xs);
             else
-                hipLaunchKernelGGL((k_bwd_wave<KIND, 1>), grid, dim3(256), 0, st, D.sdesc, g.first, g.count, D.st_idx,
+                hipLaunchKernelGGL((k_bwd_wave<KIND, 1>), grid, dim3(256), 0, st, D.sd(), g.first, g.count, D.st_idx,
                                    D.pool_pm, X, nrhs, D.pm_stride, xs);
         } else {
             constexpr int KT = 8;                   // right-hand sides per wave: the panel is read once per tile
             dim3 grid((unsigned) ((g.count + 3) / 4), (unsigned) D.batch, (unsigned) ((nrhs + KT - 1) / KT));
             if (forward)
-                hipLaunchKernelGGL((k_fwd_wave<KIND, KT>), grid, dim3(256), 0, st, D.sdesc, g.first, g.count, D.fasm_src,
+                hipLaunchKernelGGL((k_fwd_wave<KIND, KT>), grid, dim3(256), 0, st, D.sd(), g.first, g.count, D.fasm_src,
                                    D.fasm_tgt, D.flong_src, D.pool_pm, D.cv, X, nrhs, D.pm_stride, cvs, xs);
             else
-                hipLaunchKernelGGL((k_bwd_wave<KIND, KT>), grid, dim3(256), 0, st, D.sdesc, g.first, g.count, D.st_idx,
+                hipLaunchKernelGGL((k_bwd_wave<KIND, KT>), grid, dim3(256), 0, st, D.sd(), g.first, g.count, D.st_idx,
                                    D.pool_pm, X, nrhs, D.pm_stride, xs);
         }
     } else if (g.cls == SK_BIG) {
@@ -3814,10 +3779,10 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
         dim3 grid((unsigned) g.count, (unsigned) D.batch, (unsigned) nrhs);
         const size_t lds = (size_t) (g.max_r + 1 + SOLVE_BW) * sizeof(double);
         if (forward)
-            hipLaunchKernelGGL((k_fwd_blk<KIND>), grid, dim3(256), lds, st, D.sdesc, g.first, D.fasm_src,
+            hipLaunchKernelGGL((k_fwd_blk<KIND>), grid, dim3(256), lds, st, D.sd(), g.first, D.fasm_src,
                                D.fasm_tgt, D.flong_src, D.pool_pm, D.cv, X, nrhs, D.pm_stride, cvs, xs);
         else
-            hipLaunchKernelGGL((k_bwd_blk<KIND>), grid, dim3(256), lds, st, D.sdesc, g.first, D.st_idx,
+            hipLaunchKernelGGL((k_bwd_blk<KIND>), grid, dim3(256), lds, st, D.sd(), g.first, D.st_idx,
                                D.pool_pm, X, nrhs, D.pm_stride, xs);
     }
     CS3_LAUNCH_CHECK();
@@ -3948,15 +3913,22 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
                                       const std::vector<LaunchGroup> &all_sgroups, double inv_tol, double *X, int nrhs,
                                       hipStream_t st, ForkJoin &fj)
 {
+    hipError_t e;
+    if (!D.sub_tiers.empty() && !D.sd_active) {
+        // a bottom forest under the factorisation, but sweeps on the level schedule of the whole tree (several right-hand
+        // sides): the two number their levels differently, so nothing is overlapped
+        if ((e = launch_factor_levels(D, all_fgroups, inv_tol, st, fj)) != hipSuccess) return e;
+        return launch_solve_levels(D, all_sgroups, X, nrhs, true, st, fj);
+    }
     const std::vector<LaunchGroup> fgroups = factor_groups(D, all_fgroups);
     const std::vector<LaunchGroup> sgroups = sweep_groups(all_sgroups, nrhs, D.batch);
     fj.rewind();
-    hipError_t e;
     const int nlevels = fgroups.empty() ? 0 : fgroups.back().level + 1;
     std::vector<long long> tail(nlevels + 1, 0), head(nlevels + 1, 0);   // factor cost of levels >= l; sweep cost of levels < l
     for (const LaunchGroup &g : fgroups) tail[g.level] += factor_group_cost(g);
     for (int l = nlevels - 1; l >= 0; --l) tail[l] += tail[l + 1];
-    for (const LaunchGroup &g : sgroups) head[g.level + 1] += sweep_group_cost(g);
+    // (a tier of the bottom forest whose factor launch carries the forward sweep has nothing left to sweep)
+    for (const LaunchGroup &g : sgroups) head[g.level + 1] += (g.cls == SK_SUB && D.fwd_in_factor) ? 0 : sweep_group_cost(g);
     for (int l = 0; l < nlevels; ++l) head[l + 1] += head[l];
     int fork_level = -1;
     static const bool overlap = !(getenv("CS3_NO_OVERLAP") && getenv("CS3_NO_OVERLAP")[0] == '1');
@@ -3967,6 +3939,7 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
     auto sweep = [&](int lo, int hi, hipStream_t s) -> hipError_t {      // forward sweep of levels lo..hi
         for (const LaunchGroup &g : sgroups) {
             if (g.level < lo || g.level > hi) continue;
+            if (g.cls == SK_SUB && D.fwd_in_factor) continue;
             hipError_t se = (D.kind == CS3_LU) ? launch_solve_group<CS3_LU>(D, g, X, nrhs, true, s)
                                                : launch_solve_group<CS3_CHOLESKY>(D, g, X, nrhs, true, s);
             if (se != hipSuccess) return se;
@@ -4134,9 +4107,11 @@ hipError_t launch_prologue(const DeviceFactor &D, const double *ax_src, const do
 {
     const long long nzero = D.zero_big ? D.vals_size - D.big_begin : 0;     // k_front_wg zeroes its own buffer
     const long long nax = (ax_src && ax_src != D.ax) ? D.batch * D.nnz_a : 0;
-    const long long total = nzero * D.batch + nax + (x_src ? D.n * (long long) nrhs * D.batch : 0);
+    const long long nf = ax_src ? D.n_sub_a : 0;
+    const long long total = std::max(nzero * D.batch + nax + (x_src ? D.n * (long long) nrhs * D.batch : 0), nf * D.batch);
     hipLaunchKernelGGL(k_prologue, dim3(grid_for(std::max<long long>(total, 1), 256)), dim3(256), 0, st, D.status, D.pool_pm,
-                       D.big_begin, nzero, D.pm_stride, D.batch, ax_src, D.ax, nax, x_src, D.xp, D.q, D.n, nrhs);
+                       D.big_begin, nzero, D.pm_stride, D.batch, ax_src, D.ax, nax, x_src, D.xp, D.q, D.n, nrhs,
+                       D.sub_a_src, D.axf, nf, D.nnz_a);
     CS3_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -139,6 +139,200 @@ int front_class(i64 r, i64 w, bool split_small, bool interleave)
     return FC_BIG;
 }
 
+// ---------------------------------------------------------- bottom forest --
+// Step 6b of the analysis (see cs3_internal.hpp): tiers of tasks.  Everything here works on supernode orders and the
+// supernodal tree only; pool offsets and the entries of A are filled in later (fill_forest, after step 9).
+struct ForestLimits {
+    i64 fronts = 64;            // fronts per task (their descriptors, child and row lists are staged in LDS)
+    i64 arena = 5000;           // doubles: contribution blocks nb x (nb + 1) of a task that stay in its LDS (40 KB)
+    i64 bins = 256;             // tasks per launch to aim for: one workgroup per CU
+    i64 max_tiers = 4;
+    i64 coop_w = 6;             // fronts with this many pivots or more are shared by four waves (forest.hip) ...
+    i64 coop_level = 4;         // ... on local levels of at most this many fronts: a fuller level keeps every wave busy with a
+                                //     front of its own, and sharing only adds the hand-overs (measured: the leaf level of the
+                                //     slowest task of config 3 took 114 k cycles shared, 50 k one wave per front)
+};
+
+static ForestLimits forest_limits()
+{
+    ForestLimits L;
+    if (const char *e = std::getenv("CS3_SUB_FRONTS")) L.fronts = std::max<i64>(1, std::atoll(e));
+    if (const char *e = std::getenv("CS3_SUB_ARENA")) L.arena = std::max<i64>(64, std::atoll(e));
+    if (const char *e = std::getenv("CS3_SUB_BINS")) L.bins = std::max<i64>(1, std::atoll(e));
+    if (const char *e = std::getenv("CS3_SUB_TIERS")) L.max_tiers = std::max<i64>(0, std::atoll(e));
+    if (const char *e = std::getenv("CS3_SUB_COOP_W")) L.coop_w = std::max<i64>(1, std::atoll(e));
+    if (const char *e = std::getenv("CS3_SUB_COOP_LEVEL")) L.coop_level = std::max<i64>(0, std::atoll(e));
+    return L;
+}
+
+// Chooses the forest: S.sn_tier, S.sub_tiers, S.sub_tasks, S.sub_sn (fronts in task order, by local level), S.sub_lvl.
+static void build_forest(Symbolic &S, const ForestLimits &lim)
+{
+    const i32 ns = S.nsuper;
+    S.sn_tier.assign(ns, -1);
+    S.sub_tiers.clear(); S.sub_tasks.clear(); S.sub_sn.clear(); S.sub_lvl.clear();
+    auto width = [&](i32 s) -> i64 { return S.sn_ptr[s + 1] - S.sn_ptr[s]; };
+    auto order_r = [&](i32 s) -> i64 { return S.st_ptr[s + 1] - S.st_ptr[s]; };
+    std::vector<char> ok(ns);
+    std::vector<i64> nf(ns), ar(ns);
+    std::vector<i32> hgt(ns), root_of(ns), task_of(ns, -1);
+    struct Bin { i64 nf = 0, ar = 0; std::vector<i32> roots; };
+    for (i64 tier = 0; tier < lim.max_tiers; ++tier) {
+        // a front qualifies when its order fits one wave and everything below it that is still unassigned qualifies
+        // and fits one task together with it (children precede parents: one pass)
+        i32 tallest = 0;
+        for (i32 s = 0; s < ns; ++s) {
+            if (S.sn_tier[s] >= 0) continue;
+            const i64 r = order_r(s), nb = r - width(s);
+            ok[s] = r <= SUB_RMAX; nf[s] = 1; ar[s] = nb * (nb + 1); hgt[s] = 0;
+            for (i32 cp = S.child_ptr[s]; cp < S.child_ptr[s + 1]; ++cp) {
+                const i32 c = S.child_idx[cp];
+                if (S.sn_tier[c] >= 0) continue;                // done in a tier below: its block comes from the pool
+                ok[s] = ok[s] && ok[c];
+                nf[s] += nf[c]; ar[s] += ar[c]; hgt[s] = std::max(hgt[s], hgt[c] + 1);
+            }
+            if (nf[s] > lim.fronts || ar[s] > lim.arena) ok[s] = 0;
+            if (ok[s]) tallest = std::max(tallest, hgt[s]);
+        }
+        // a tier of single fronts is a level launch with a slower kernel: leave those to the level schedule
+        if (tallest < 1) break;
+        std::vector<i32> roots;
+        for (i32 s = 0; s < ns; ++s)
+            if (S.sn_tier[s] < 0 && ok[s] && (S.sn_parent[s] < 0 || !ok[S.sn_parent[s]])) roots.push_back(s);
+        if (roots.empty()) break;
+        // parents before children is what marks the members: walk down from the roots (ids descend along a subtree)
+        for (i32 s = ns - 1; s >= 0; --s) {
+            if (S.sn_tier[s] >= 0 || !ok[s]) continue;
+            const i32 p = S.sn_parent[s];
+            root_of[s] = (p >= 0 && S.sn_tier[p] == tier && ok[p]) ? root_of[p] : s;
+            S.sn_tier[s] = (i32) tier;
+        }
+        // tasks: the largest subtrees get a workgroup each; once there are `bins` of them the rest joins the least
+        // loaded task that still has room
+        std::stable_sort(roots.begin(), roots.end(), [&](i32 a, i32 b) { return nf[a] > nf[b]; });
+        std::vector<Bin> bins;
+        for (i32 rt : roots) {
+            i64 best = -1;
+            if ((i64) bins.size() >= lim.bins)
+                for (size_t b = 0; b < bins.size(); ++b)
+                    if (bins[b].nf + nf[rt] <= lim.fronts && bins[b].ar + ar[rt] <= lim.arena &&
+                        (best < 0 || bins[b].nf < bins[(size_t) best].nf)) best = (i64) b;
+            if (best < 0) { bins.emplace_back(); best = (i64) bins.size() - 1; }
+            Bin &B = bins[(size_t) best];
+            B.nf += nf[rt]; B.ar += ar[rt]; B.roots.push_back(rt);
+        }
+        SubTier T;
+        T.task0 = (i32) S.sub_tasks.size(); T.ntasks = (i32) bins.size();
+        const i32 base_task = T.task0;
+        for (size_t b = 0; b < bins.size(); ++b)
+            for (i32 rt : bins[b].roots) task_of[rt] = base_task + (i32) b;
+        // members by task: (task, local level, id)
+        std::vector<i32> members;
+        for (i32 s = 0; s < ns; ++s) if (S.sn_tier[s] == tier) members.push_back(s);
+        std::stable_sort(members.begin(), members.end(), [&](i32 a, i32 b) {
+            const i32 ta = task_of[root_of[a]], tb = task_of[root_of[b]];
+            if (ta != tb) return ta < tb;
+            if (hgt[a] != hgt[b]) return hgt[a] < hgt[b];
+            // the shared (wide) fronts of a local level first, then the others, largest first: they start at once and the
+            // small ones fill the other waves
+            const bool ca = width(a) >= lim.coop_w, cb = width(b) >= lim.coop_w;
+            if (ca != cb) return ca;
+            return width(a) * order_r(a) > width(b) * order_r(b);
+        });
+        size_t m = 0;
+        for (size_t b = 0; b < bins.size(); ++b) {
+            SubTask K{};
+            K.front0 = (i32) S.sub_sn.size(); K.lvl0 = (i32) S.sub_lvl.size();
+            // per local level two entries: its first front (relative to front0) and how many of its leading fronts are shared
+            i32 cur = -1;
+            while (m < members.size() && task_of[root_of[members[m]]] == base_task + (i32) b) {
+                const i32 s = members[m++];
+                while (cur < hgt[s]) { S.sub_lvl.push_back((i32) S.sub_sn.size() - K.front0); S.sub_lvl.push_back(0); ++cur; }
+                S.sub_sn.push_back(s);
+                if (width(s) >= lim.coop_w) ++S.sub_lvl.back();
+                T.max_r = std::max<i32>(T.max_r, (i32) order_r(s));
+            }
+            K.nfronts = (i32) S.sub_sn.size() - K.front0;
+            K.nlevels = cur + 1;
+            S.sub_lvl.push_back(K.nfronts);
+            for (i32 l = 0; l < K.nlevels; ++l)                 // full levels: nobody shares
+                if (S.sub_lvl[K.lvl0 + 2 * l + 2] - S.sub_lvl[K.lvl0 + 2 * l] > lim.coop_level) S.sub_lvl[K.lvl0 + 2 * l + 1] = 0;
+            S.sub_tasks.push_back(K);
+            T.max_fronts = std::max(T.max_fronts, K.nfronts);
+            T.max_levels = std::max(T.max_levels, K.nlevels);
+        }
+        S.sub_tiers.push_back(T);
+    }
+}
+
+// Second half, once the pool is laid out and the entries of A are sorted to their fronts: descriptors, child and row
+// lists, scatter lists of A.  from_a[s] = (target in the LDS image, ~entry of Ax) of forest front s.
+template <class Item>
+static void fill_forest(Symbolic &S, std::vector<std::vector<Item>> &from_a)
+{
+    const size_t nfr = S.sub_sn.size();
+    S.sub_fronts.assign(nfr, SubFront{});
+    S.sub_rel.clear(); S.sub_st.clear(); S.sub_child.clear(); S.sub_a_tgt.clear(); S.sub_a_src.clear();
+    std::vector<i32> pos(S.nsuper, -1);
+    for (size_t f = 0; f < nfr; ++f) pos[S.sub_sn[f]] = (i32) f;
+    for (SubTier &T : S.sub_tiers) {
+        for (i32 k = T.task0; k < T.task0 + T.ntasks; ++k) {
+            SubTask &K = S.sub_tasks[k];
+            K.rel0 = (i32) S.sub_rel.size(); K.child0 = (i32) S.sub_child.size() / 4;
+            i64 arena = 0, varena = 0;
+            for (i32 f = K.front0; f < K.front0 + K.nfronts; ++f) {
+                const i32 s = S.sub_sn[f];
+                SubFront &d = S.sub_fronts[f];
+                const i64 r = S.st_ptr[s + 1] - S.st_ptr[s], w = S.sn_ptr[s + 1] - S.sn_ptr[s], nb = r - w;
+                d.lpan = (i32) S.lpan_off[s]; d.upan = (i32) S.upan_off[s];
+                d.c0 = S.sn_ptr[s]; d.r = (i32) r; d.w = (i32) w;
+                d.cv = (i32) S.cv_off[s];
+                d.st = (i32) S.st_ptr[s];
+                d.u_sj = S.u_sj[s];
+                const i32 p = S.sn_parent[s];
+                const bool inside = p >= 0 && pos[p] >= K.front0 && pos[p] < K.front0 + K.nfronts;
+                d.parent = inside ? pos[p] : -1;
+                if (inside) { d.cb = (i32) ~arena; arena += nb * (nb + 1); }
+                else d.cb = (p >= 0) ? (i32) S.cb_off[s] : INT32_MIN;
+                d.arena = (i32) varena; varena += nb;
+                d.rel = (i32) S.sub_rel.size();
+                if (p >= 0)
+                    for (i64 i = 0; i < nb; ++i) {
+                        S.sub_rel.push_back(S.rel_idx[S.rel_ptr[s] + i]);
+                        S.sub_st.push_back(S.st_idx[S.st_ptr[s] + w + i]);
+                    }
+                // children: 4 ints each, filled in below (a child sits in front of its parent in the array, so its own
+                // descriptor is complete by now)
+                d.child_begin = (i32) S.sub_child.size() / 4;
+                for (i32 cp = S.child_ptr[s]; cp < S.child_ptr[s + 1]; ++cp) {
+                    const i32 c = S.child_idx[cp];
+                    if (pos[c] < 0 || pos[c] >= f) throw std::runtime_error("analyze: a forest front has a child outside the forest");
+                    const SubFront &cd = S.sub_fronts[pos[c]];
+                    const bool mine = pos[c] >= K.front0;
+                    const i32 nbc = cd.r - cd.w;
+                    S.sub_child.push_back(nbc | (mine ? 1 << 16 : 0));
+                    S.sub_child.push_back(mine ? cd.rel - K.rel0 : cd.rel);      // row map: in the task's staged slice / in sub_rel
+                    S.sub_child.push_back(mine ? ~cd.cb : cd.cb);                // block: arena offset / pool offset
+                    S.sub_child.push_back(mine ? cd.arena : cd.cv);              // vector: arena of the stand-alone sweep / cv pool
+                }
+                d.child_count = (i32) S.sub_child.size() / 4 - d.child_begin;
+                d.a_begin = (i32) S.sub_a_tgt.size();
+                // (target: row | column << 8 of the front; from_a holds row + column (r | 1))
+                for (const Item &it : from_a[s]) {
+                    const i32 ld = (i32) (r | 1);
+                    S.sub_a_tgt.push_back((it.tgt % ld) | ((it.tgt / ld) << 8));
+                    S.sub_a_src.push_back(~it.src);
+                }
+                d.a_count = (i32) S.sub_a_tgt.size() - d.a_begin;
+                std::vector<Item>().swap(from_a[s]);
+            }
+            K.nrel = (i32) S.sub_rel.size() - K.rel0; K.nchild = (i32) S.sub_child.size() / 4 - K.child0;
+            T.max_rel = std::max(T.max_rel, K.nrel); T.max_child = std::max(T.max_child, K.nchild);
+            T.max_arena = std::max<i32>(T.max_arena, (i32) arena); T.max_varena = std::max<i32>(T.max_varena, (i32) varena);
+        }
+    }
+}
+
 }  // namespace
 
 void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
@@ -413,6 +607,19 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         for (i64 p = fst_ptr[t] + wt; p < fst_ptr[t + 1]; ++p) st[cnt++] = fst_idx[p];
     }
 
+    // ---- 6b. the bottom forest: subtrees of small fronts that one workgroup walks in one launch (single matrices and
+    //          small batches: a large batch fills the chip level by level and runs its small fronts lane = matrix)
+    {
+        static const bool sub_on = !(std::getenv("CS3_SUBTREE") && std::getenv("CS3_SUBTREE")[0] == '0');
+        static const i64 sub_max_batch = std::getenv("CS3_SUB_MAX_BATCH") ? std::atoll(std::getenv("CS3_SUB_MAX_BATCH")) : 1;
+        S.sn_tier.assign(ns, -1);
+        if (sub_on && S.batch <= sub_max_batch) build_forest(S, forest_limits());
+    }
+    const i32 ntiers = (i32) S.sub_tiers.size();
+    auto in_forest = [&](i32 s) { return S.sn_tier[s] >= 0; };
+    // (a forest front whose parent sits in the same tier sits in the same task: its contribution block never leaves the LDS)
+    auto block_stays_in_lds = [&](i32 s) { const i32 p = S.sn_parent[s]; return in_forest(s) && p >= 0 && S.sn_tier[p] == S.sn_tier[s]; };
+
     // ---- 7. size classes, pool layout, child -> parent relative indices
     S.sn_class.assign(ns, 0);
     S.lpan_off.assign(ns, 0); S.upan_off.assign(ns, 0); S.cb_off.assign(ns, 0); S.cv_off.assign(ns, 0);
@@ -427,7 +634,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     const bool interleave = S.batch >= il_min_batch;
     for (i32 s = 0; s < ns; ++s) {                   // interleaved region first: dense r x r buffers of the FC_IL fronts
         const i64 w = width(s), r = order_r(s);
-        if (front_class(r, w, S.batch >= 8, interleave) != FC_IL) continue;
+        if (in_forest(s) || front_class(r, w, S.batch >= 8, interleave) != FC_IL) continue;
         S.lpan_off[s] = voff;
         S.upan_off[s] = voff + w * r; S.u_sk[s] = 1; S.u_sj[s] = (i32) r;
         S.cb_off[s] = voff + w + w * r; S.cb_ld[s] = (i32) r;
@@ -437,8 +644,8 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     // a handful of smaller fronts on the same level then ride that chain (dense r x r buffers, the same launches) instead of
     // a launch of their own beside it -- the fork and the join across hardware queues cost the level 12-17 us, the chain
     // takes no longer for two more tiles (round 2, profiles/r02_timeline_fused_step.json).  CS3_RIDE_MAX=0: off.
-    std::vector<i32> lvl(ns, 0);
-    for (i32 s = 0; s < ns; ++s) { const i32 p = S.sn_parent[s]; if (p >= 0) lvl[p] = std::max(lvl[p], lvl[s] + 1); }
+    std::vector<i32> lvl(ns, 0);             // height above the forest (the whole tree when there is none)
+    for (i32 s = 0; s < ns; ++s) { const i32 p = S.sn_parent[s]; if (p >= 0 && !in_forest(s)) lvl[p] = std::max(lvl[p], lvl[s] + 1); }
     std::vector<char> ride(ns, 0);
     {
         static const i64 ride_max = std::getenv("CS3_RIDE_MAX") ? std::atoll(std::getenv("CS3_RIDE_MAX")) : 8;
@@ -446,6 +653,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         for (i32 s = 0; s < ns; ++s) nl = std::max(nl, lvl[s] + 1);
         std::vector<i64> big_w(nl, 0), small_n(nl, 0), small_w(nl, 0);
         for (i32 s = 0; s < ns && S.batch == 1; ++s) {
+            if (in_forest(s)) continue;
             const int c = front_class(order_r(s), width(s), false, false);
             if (c == FC_BIG) big_w[lvl[s]] = std::max(big_w[lvl[s]], width(s));
             else { ++small_n[lvl[s]]; small_w[lvl[s]] = std::max(small_w[lvl[s]], width(s)); }
@@ -453,16 +661,17 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         for (i32 s = 0; s < ns && S.batch == 1; ++s) {
             const i32 l = lvl[s];
             // (no more block launches than the chain has: the riders' pivots fit the blocks it runs anyway)
-            ride[s] = big_w[l] > 0 && small_n[l] <= ride_max && (small_w[l] + 31) / 32 <= (big_w[l] + 31) / 32;
+            ride[s] = !in_forest(s) && big_w[l] > 0 && small_n[l] <= ride_max && (small_w[l] + 31) / 32 <= (big_w[l] + 31) / 32;
         }
     }
     auto class_of = [&](i32 s) -> int {
+        if (in_forest(s)) return (int) FC_SUB;
         return ride[s] ? (int) FC_BIG : front_class(order_r(s), width(s), S.batch >= 8, interleave);
     };
     S.sn_il_panels.assign(ns, 0);
     for (i32 s = 0; s < ns && interleave; ++s) {     // ... then the panels of the lane = row fronts that sweep lane = matrix
         const i64 w = width(s), r = order_r(s);
-        if (front_class(r, w, S.batch >= 8, interleave) != FC_R32 || r > il_sweep_rmax()) continue;
+        if (in_forest(s) || front_class(r, w, S.batch >= 8, interleave) != FC_R32 || r > il_sweep_rmax()) continue;
         S.sn_il_panels[s] = 1;
         S.lpan_off[s] = voff;                        // dense addressing (i, j) -> i + j r like the FC_IL fronts: L in the
         if (kind == CS3_LU) { S.upan_off[s] = voff + w * r; S.u_sk[s] = 1; S.u_sj[s] = (i32) r; }     // first w columns, U12
@@ -499,7 +708,9 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     for (i32 s = 0; s < ns; ++s) {                   // compact contribution blocks
         if (S.sn_class[s] == FC_BIG || S.sn_class[s] == FC_IL) continue;
         const i64 nb = order_r(s) - width(s);
-        S.cb_off[s] = cboff; S.cb_ld[s] = (i32) nb;
+        S.cb_ld[s] = (i32) nb;
+        if (block_stays_in_lds(s)) { S.cb_off[s] = -1; continue; }
+        S.cb_off[s] = cboff;
         cboff += nb * nb;
     }
     S.cb_size = cboff - voff; S.cv_size = cvoff; S.pool_size = cboff;
@@ -531,6 +742,9 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     }
     S.nlevels = 0;
     for (i32 s = 0; s < ns; ++s) S.nlevels = std::max(S.nlevels, S.sn_level[s] + 1);
+    // the factor schedule (and the sweeps of one right-hand side): tiers of the forest, then the levels above it
+    S.sn_tlevel.assign(ns, 0);
+    for (i32 s = 0; s < ns; ++s) S.sn_tlevel[s] = in_forest(s) ? S.sn_tier[s] : ntiers + lvl[s];
 
     // ---- 9. assembly lists: every entry of a front is the sum of its sources
     auto find_row = [&](i32 s, i32 row) -> i64 {
@@ -604,6 +818,11 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     {
         std::vector<Item> items;
         for (i32 s = 0; s < ns; ++s) {
+            if (in_forest(s)) {                 // assembled by extend-add inside its task (fill_forest below): no gather list
+                S.asm_ptr[s + 1] = (i64) S.asm_tgt.size();
+                S.ila_ptr[s + 1] = (i64) (S.ila_pairs.size() / 2);
+                continue;
+            }
             items.assign(from_a[s].begin(), from_a[s].end());
             std::vector<Item>().swap(from_a[s]);
             for (i32 cp = S.child_ptr[s]; cp < S.child_ptr[s + 1]; ++cp) {
@@ -638,19 +857,20 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         }
     }
     if (S.asm_tgt.size() >= ((size_t) 1 << 31)) throw std::runtime_error("analyze: assembly list exceeds 32-bit offsets");
+    if (ntiers > 0) fill_forest(S, from_a);
 
     // ---- 10. launch groups by (level, size class)
     S.sched.resize(ns);
     std::iota(S.sched.begin(), S.sched.end(), 0);
     std::stable_sort(S.sched.begin(), S.sched.end(), [&](i32 a, i32 b) {
-        if (S.sn_level[a] != S.sn_level[b]) return S.sn_level[a] < S.sn_level[b];
+        if (S.sn_tlevel[a] != S.sn_tlevel[b]) return S.sn_tlevel[a] < S.sn_tlevel[b];
         return S.sn_class[a] < S.sn_class[b];
     });
     S.groups.clear();
     for (i32 t = 0; t < ns; ) {
         i32 s = S.sched[t];
-        LaunchGroup g{S.sn_level[s], S.sn_class[s], t, 0, 0, 0, 0};
-        while (t < ns && S.sn_level[S.sched[t]] == g.level && S.sn_class[S.sched[t]] == g.cls) {
+        LaunchGroup g{S.sn_tlevel[s], S.sn_class[s], t, 0, 0, 0, 0};
+        while (t < ns && S.sn_tlevel[S.sched[t]] == g.level && S.sn_class[S.sched[t]] == g.cls) {
             const i32 f = S.sched[t];
             g.max_r = std::max<i32>(g.max_r, (i32) order_r(f));
             g.max_w = std::max<i32>(g.max_w, (i32) width(f));
@@ -658,17 +878,13 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
             ++t;
         }
         g.count = t - g.first;
-        g.need = INT32_MAX;
-        for (i32 u = g.first; u < t; ++u) {
-            const i32 p = S.sn_parent[S.sched[u]];
-            if (p >= 0) g.need = std::min(g.need, S.sn_level[p]);
-        }
+        if (g.cls == FC_SUB) { g.first = g.level; g.count = S.sub_tiers[g.level].ntasks; }   // a tier: `first` names it, one workgroup per task
         S.groups.push_back(g);
     }
     if (std::getenv("CS3_DEBUG_GROUPS"))
         for (const LaunchGroup &g : S.groups)
-            std::fprintf(stderr, "factor group level %d class %d count %d max_r %d max_w %d needed at level %d\n", g.level, g.cls,
-                         g.count, g.max_r, g.max_w, g.need == INT32_MAX ? -1 : g.need);
+            std::fprintf(stderr, "factor group level %d class %d count %d max_r %d max_w %d\n", g.level, g.cls,
+                         g.count, g.max_r, g.max_w);
 
     // ---- 10b. forward-solve gather lists and the solve schedule
     S.fasm_ptr.assign(ns + 1, 0);
@@ -782,12 +998,43 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         S.sgroups.push_back(g);
     }
 
+    // one right-hand side with a forest: the sweeps follow the factor schedule -- one launch per tier (SK_SUB: `first`
+    // names the tier), then the levels above the forest
+    S.ssched1.clear(); S.sgroups1.clear();
+    if (ntiers > 0) {
+        auto kind1 = [&](i32 s) { return in_forest(s) ? (int) SK_SUB : solve_kind(s); };
+        S.ssched1.resize(ns);
+        std::iota(S.ssched1.begin(), S.ssched1.end(), 0);
+        std::stable_sort(S.ssched1.begin(), S.ssched1.end(), [&](i32 a, i32 b) {
+            if (S.sn_tlevel[a] != S.sn_tlevel[b]) return S.sn_tlevel[a] < S.sn_tlevel[b];
+            return kind1(a) < kind1(b);
+        });
+        for (i32 t = 0; t < ns; ) {
+            i32 s = S.ssched1[t];
+            LaunchGroup g{S.sn_tlevel[s], kind1(s), t, 0, 0, 0, 0};
+            while (t < ns && S.sn_tlevel[S.ssched1[t]] == g.level && kind1(S.ssched1[t]) == g.cls) {
+                const i32 f = S.ssched1[t];
+                g.max_r = std::max<i32>(g.max_r, (i32) order_r(f));
+                g.max_w = std::max<i32>(g.max_w, (i32) width(f));
+                ++t;
+            }
+            g.count = t - g.first;
+            if (g.cls == SK_SUB) { g.first = g.level; g.count = S.sub_tiers[g.level].ntasks; }
+            S.sgroups1.push_back(g);
+        }
+    }
+
     if (getenv("CS3_DUMP_GROUPS")) {
         for (const LaunchGroup &g : S.groups)
             fprintf(stderr, "factor level %2d cls %d count %6d max_r %4d max_w %4d max_asm %lld\n", g.level, g.cls, g.count,
                     g.max_r, g.max_w, (long long) g.max_asm);
         for (const LaunchGroup &g : S.sgroups)
             fprintf(stderr, "solve  level %2d kind %d count %6d max_r %4d max_w %4d\n", g.level, g.cls, g.count, g.max_r, g.max_w);
+        for (const LaunchGroup &g : S.sgroups1)
+            fprintf(stderr, "solve1 level %2d kind %d count %6d max_r %4d max_w %4d\n", g.level, g.cls, g.count, g.max_r, g.max_w);
+        for (const SubTier &T : S.sub_tiers)
+            fprintf(stderr, "tier: %d tasks, max fronts %d levels %d rel %d child %d arena %d max_r %d\n", T.ntasks, T.max_fronts,
+                    T.max_levels, T.max_rel, T.max_child, T.max_arena, T.max_r);
     }
 
     // ---- 11. factors in CSC form: L diagonal first, U diagonal last.  Only the

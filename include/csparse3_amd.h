@@ -172,6 +172,10 @@ int cs3_debug_front_stamps(cs3_handle h, int64_t *out);
 int cs3_debug_poison_lds(void *stream);
 /* Factorisation schedule: supernode id, front order r and width w per schedule slot. */
 int cs3_debug_schedule(cs3_handle h, int32_t *sched, int32_t *front_r, int32_t *front_w);
+/* The bottom forest (subtrees of small fronts walked by one workgroup each): returns the number of forest
+ * fronts (0: no forest) and, for arrays that are not null, per forest front in task order its supernode, its task, its local
+ * level inside the task and its tier (= launch).  Diagnostics and tests. */
+int64_t cs3_debug_forest(cs3_handle h, int32_t *supernode, int32_t *task, int32_t *level, int32_t *tier);
 
 /* ---- general triangular solves on caller-supplied CSC factors -----------
  * cs_lsolve / cs_usolve lineage, the csc_lsolve_f(n, Lp, Li, Lx, x) shape of

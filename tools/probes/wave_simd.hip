@@ -1,0 +1,17 @@
+// Probe: which SIMD each wave of a 512-thread workgroup lands on (gfx950): s_getreg HW_ID.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+__global__ void k(unsigned *out)
+{
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 8 + (threadIdx.x >> 6)] = id;
+}
+int main()
+{
+    unsigned *d; hipMalloc(&d, 4 * 8 * sizeof(unsigned));
+    hipLaunchKernelGGL(k, dim3(4), dim3(512), 0, 0, d);
+    unsigned h[32]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    for (int b = 0; b < 4; ++b) { printf("block %d:", b); for (int w = 0; w < 8; ++w) printf(" w%d: wave_id %u simd %u cu %u", w, h[b*8+w] & 15, (h[b*8+w] >> 4) & 3, (h[b*8+w] >> 8) & 15); printf("\n"); }
+    return 0;
+}

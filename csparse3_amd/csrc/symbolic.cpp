@@ -146,7 +146,12 @@ struct ForestLimits {
     i64 fronts = 64;            // fronts per task (their descriptors, child and row lists are staged in LDS)
     i64 arena = 5000;           // doubles: contribution blocks nb x (nb + 1) of a task that stay in its LDS (40 KB)
     i64 bins = 256;             // tasks per launch to aim for: one workgroup per CU
-    i64 max_tiers = 4;
+    // One tier of SHALLOW subtrees: a task that holds a tall chain runs as long as the chain, and everything above the
+    // tier waits for it, while in the level schedule the upper fronts of a chain share their launches with the rest of
+    // their level (measured on config 3: unlimited height and 2 tiers 0.663 ms per step, height 4 and 1 tier 0.608,
+    // no forest 0.641).
+    i64 max_tiers = 1;
+    i64 max_height = 4;         // tallest subtree (local levels - 1) a task may hold
     i64 coop_w = 6;             // fronts with this many pivots or more are shared by four waves (forest.hip) ...
     i64 coop_level = 4;         // ... on local levels of at most this many fronts: a fuller level keeps every wave busy with a
                                 //     front of its own, and sharing only adds the hand-overs (measured: the leaf level of the
@@ -160,6 +165,7 @@ static ForestLimits forest_limits()
     if (const char *e = std::getenv("CS3_SUB_ARENA")) L.arena = std::max<i64>(64, std::atoll(e));
     if (const char *e = std::getenv("CS3_SUB_BINS")) L.bins = std::max<i64>(1, std::atoll(e));
     if (const char *e = std::getenv("CS3_SUB_TIERS")) L.max_tiers = std::max<i64>(0, std::atoll(e));
+    if (const char *e = std::getenv("CS3_SUB_HEIGHT")) L.max_height = std::max<i64>(1, std::atoll(e));
     if (const char *e = std::getenv("CS3_SUB_COOP_W")) L.coop_w = std::max<i64>(1, std::atoll(e));
     if (const char *e = std::getenv("CS3_SUB_COOP_LEVEL")) L.coop_level = std::max<i64>(0, std::atoll(e));
     return L;
@@ -191,7 +197,7 @@ static void build_forest(Symbolic &S, const ForestLimits &lim)
                 ok[s] = ok[s] && ok[c];
                 nf[s] += nf[c]; ar[s] += ar[c]; hgt[s] = std::max(hgt[s], hgt[c] + 1);
             }
-            if (nf[s] > lim.fronts || ar[s] > lim.arena) ok[s] = 0;
+            if (nf[s] > lim.fronts || ar[s] > lim.arena || hgt[s] > lim.max_height) ok[s] = 0;
             if (ok[s]) tallest = std::max(tallest, hgt[s]);
         }
         // a tier of single fronts is a level launch with a slower kernel: leave those to the level schedule

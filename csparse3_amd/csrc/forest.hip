@@ -622,7 +622,12 @@ k_sub_factor(const SubTask *__restrict__ tasks, int task0, const SubFront *__res
             // nowhere (a select on the scalar r turns every one of these reads into a branch with a wait of its own)
             const int li = lane < r ? lane : 0;
 #pragma unroll
-            for (int j = 0; j < SUB_NC; ++j) row[j] = F[li + min(j, r) * ld];
+            for (int j0 = 0; j0 < SUB_NC; j0 += 8) {
+                if (j0 < r) {                                   // (register groups beyond the front are never used)
+#pragma unroll
+                    for (int j = j0; j < j0 + 8; ++j) row[j] = F[li + min(j, r) * ld];
+                }
+            }
             if (RHS) rhs = F[li + r * ld];
         }
         CS3_SSTAMP(f, 3);
@@ -639,40 +644,57 @@ k_sub_factor(const SubTask *__restrict__ tasks, int task0, const SubFront *__res
             // columns w .. r - 1: pivot rows hold U12 (global), the others the contribution block (arena or pool).
             // One lane-dependent region per destination, wave-uniform branches per column inside it: a predicate per
             // register column costs ten instructions, and there are 96 of them.
+            // (groups of eight register columns behind one wave-uniform branch each: a small front skips most of them)
             const bool is_u = lane < w;
             if (live) {
                 double *Lp = pool + ds.lpan + lane;
 #pragma unroll
-                for (int j = 0; j < SUB_NC; ++j)
-                    if (j < w) {
-                        if (KIND == CS3_LU) Lp[j * r] = row[j];
-                        else if (lane >= j) Lp[j * r] = row[j];
+                for (int j0 = 0; j0 < SUB_NC; j0 += 8)
+                    if (j0 < w) {
+#pragma unroll
+                        for (int j = j0; j < j0 + 8; ++j)
+                            if (j < w) {
+                                if (KIND == CS3_LU) Lp[j * r] = row[j];
+                                else if (lane >= j) Lp[j * r] = row[j];
+                            }
                     }
             }
             CS3_SSTAMP(f, 6);
             if (KIND == CS3_LU && is_u) {
                 double *Up = pool + ds.upan + lane;
 #pragma unroll
-                for (int j = 0; j < SUB_NC; ++j)
-                    if (j >= w && j < r) Up[(j - w) * ds.u_sj] = row[j];
+                for (int j0 = 0; j0 < SUB_NC; j0 += 8)
+                    if (j0 + 8 > w && j0 < r) {
+#pragma unroll
+                        for (int j = j0; j < j0 + 8; ++j)
+                            if (j >= w && j < r) Up[(j - w) * ds.u_sj] = row[j];
+                    }
             }
             CS3_SSTAMP(f, 7);
             if (live && !is_u) {
                 if (cb_lds) {
                     double *cbl = arena + ~cbo + (lane - w);
 #pragma unroll
-                    for (int j = 0; j < SUB_NC; ++j)
-                        if (j >= w && j < r) {
-                            if (KIND == CS3_LU) cbl[(j - w) * nb] = row[j];
-                            else if (lane >= j) cbl[(j - w) * nb] = row[j];
+                    for (int j0 = 0; j0 < SUB_NC; j0 += 8)
+                        if (j0 + 8 > w && j0 < r) {
+#pragma unroll
+                            for (int j = j0; j < j0 + 8; ++j)
+                                if (j >= w && j < r) {
+                                    if (KIND == CS3_LU) cbl[(j - w) * nb] = row[j];
+                                    else if (lane >= j) cbl[(j - w) * nb] = row[j];
+                                }
                         }
                 } else if (cb_pool) {
                     double *cbg = pool + cbo + (lane - w);
 #pragma unroll
-                    for (int j = 0; j < SUB_NC; ++j)
-                        if (j >= w && j < r) {
-                            if (KIND == CS3_LU) cbg[(j - w) * nb] = row[j];
-                            else if (lane >= j) cbg[(j - w) * nb] = row[j];
+                    for (int j0 = 0; j0 < SUB_NC; j0 += 8)
+                        if (j0 + 8 > w && j0 < r) {
+#pragma unroll
+                            for (int j = j0; j < j0 + 8; ++j)
+                                if (j >= w && j < r) {
+                                    if (KIND == CS3_LU) cbg[(j - w) * nb] = row[j];
+                                    else if (lane >= j) cbg[(j - w) * nb] = row[j];
+                                }
                         }
                 }
             }
@@ -774,7 +796,12 @@ k_sub_fwd(const SubTask *__restrict__ tasks, int task0, const SubFront *__restri
             // one and are never used: masks depend on the lane only -- a select on the scalar w would become a branch per load)
             double lk[SUB_NC];
 #pragma unroll
-            for (int k = 0; k < SUB_NC; ++k) lk[k] = load_if(L, lane + min(k, w - 1) * r, lane < r && lane > k);
+            for (int k0 = 0; k0 < SUB_NC; k0 += 8) {
+                if (k0 < w) {
+#pragma unroll
+                    for (int k = k0; k < k0 + 8; ++k) lk[k] = load_if(L, lane + min(k, w - 1) * r, lane < r && lane > k);
+                }
+            }
             double rpd = 1.0;
             if (KIND == CS3_CHOLESKY) rpd = L[(lane < w ? lane : 0) * (long long) (r + 1)];
             const double xv = load_if(X, c0 + lane, lane < w);
@@ -801,10 +828,15 @@ k_sub_fwd(const SubTask *__restrict__ tasks, int task0, const SubFront *__restri
             if (lane >= r) v = 0.0;
             if (KIND == CS3_CHOLESKY) rpd = fast_rcp(lane < w ? rpd : 1.0);
 #pragma unroll
-            for (int k = 0; k < SUB_NC; ++k) {
-                if (k < w) {
-                    if (KIND == CS3_CHOLESKY && lane == k) v *= rpd;
-                    v -= lk[k] * bcast_lane(v, k);
+            for (int k0 = 0; k0 < SUB_NC; k0 += 8) {
+                if (k0 < w) {
+#pragma unroll
+                    for (int k = k0; k < k0 + 8; ++k) {
+                        if (k < w) {
+                            if (KIND == CS3_CHOLESKY && lane == k) v *= rpd;
+                            v -= lk[k] * bcast_lane(v, k);
+                        }
+                    }
                 }
             }
             if (lane < w) X[c0 + lane] = v;
@@ -848,23 +880,39 @@ k_sub_bwd(const SubTask *__restrict__ tasks, int task0, const SubFront *__restri
             double v = load_if(X, myrow, lane < r);
             // row `lane` of M, strictly right of the diagonal
             // (columns past r repeat the last one and are never used: the masks depend on the lane only)
+            // (groups of eight columns behind one wave-uniform branch each: most fronts are small)
             double m[SUB_NC];
             const int lpan = ds.lpan, upan = ds.upan;
 #pragma unroll
-            for (int tt = 0; tt < SUB_NC; ++tt) {
-                const int tc = min(tt, r - 1);
-                int off;
-                if (KIND == CS3_LU) off = ((tc < w) ? lpan + tc * r : upan + (tc - w) * us) + lane;
-                else off = lpan + tc + lane * r;
-                m[tt] = load_if(pool, off, lane < w && lane < tt);
+            for (int t0 = 0; t0 < SUB_NC; t0 += 8) {
+                if (t0 < r) {
+#pragma unroll
+                    for (int tt = t0; tt < t0 + 8; ++tt) {
+                        const int tc = min(tt, r - 1);
+                        int off;
+                        if (KIND == CS3_LU) off = ((tc < w) ? lpan + tc * r : upan + (tc - w) * us) + lane;
+                        else off = lpan + tc + lane * r;
+                        m[tt] = load_if(pool, off, lane < w && lane < tt);
+                    }
+                }
             }
             const double rdg = recip_diag(L, lane, r, lane < w);
 #pragma unroll
-            for (int tt = 0; tt < SUB_NC; ++tt) m[tt] *= rdg;
+            for (int t0 = 0; t0 < SUB_NC; t0 += 8) {
+                if (t0 < r) {
+#pragma unroll
+                    for (int tt = t0; tt < t0 + 8; ++tt) m[tt] *= rdg;
+                }
+            }
             if (lane < w) v *= rdg;
 #pragma unroll
-            for (int tt = SUB_NC - 1; tt >= 1; --tt) {
-                if (tt < r) v -= m[tt] * bcast_lane(v, tt);
+            for (int t0 = SUB_NC - 8; t0 >= 0; t0 -= 8) {
+                if (t0 < r) {
+#pragma unroll
+                    for (int tt = t0 + 7; tt >= t0; --tt) {
+                        if (tt >= 1 && tt < r) v -= m[tt] * bcast_lane(v, tt);
+                    }
+                }
             }
             if (lane < w) X[c0 + lane] = v;
         }

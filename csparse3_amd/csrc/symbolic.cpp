@@ -153,7 +153,7 @@ struct ForestLimits {
     i64 max_tiers = 1;
     i64 max_height = 4;         // tallest subtree (local levels - 1) a task may hold
     i64 coop_w = 6;             // fronts with this many pivots or more are shared by four waves (forest.hip) ...
-    i64 coop_level = 4;         // ... on local levels of at most this many fronts: a fuller level keeps every wave busy with a
+    i64 coop_level = 2;         // ... on local levels of at most this many fronts (one round of two groups): a fuller level keeps every wave busy with a
                                 //     front of its own, and sharing only adds the hand-overs (measured: the leaf level of the
                                 //     slowest task of config 3 took 114 k cycles shared, 50 k one wave per front)
 };

@@ -57,6 +57,69 @@ class CscMat:
                 val[self.indices[p], j] = self.data[p]
         return val
 
+    # ---- operators of the reference class whose kernels live on the device (csc.py:143-346, 425-457)
+    def __getitem__(self, key):
+        """The eight slicing forms of the reference (csc.py:143-283; src/test/test2_slicing.py:6-79), same kernels, same
+        results: A[a, :], A[:, b], A[:, :], A[a, list], A[list, b], A[:, list], A[list, :], A[list, list].  The row
+        selections run cs3_csc_sub_matrix on the device and keep the reference's row numbering (a running match counter:
+        csc_numba.py:464-502, 541-578 -- csc_sub_matrix_rows is csc_sub_matrix over all columns, loop for loop); a column
+        selection copies whole columns with their original row indices (csc_sub_matrix_cols, csc_numba.py:505-538)."""
+        from collections.abc import Iterable
+        if not isinstance(key, tuple):
+            raise Exception('The indices must be a tuple :/')
+        a, b = key
+        is_int = lambda v: isinstance(v, (int, np.integer))
+        as_idx = lambda v: np.asarray([v] if is_int(v) else v, dtype=np.int32)
+        if is_int(a) and is_int(b):
+            raise NotImplementedError('Single value extraction not implemented')       # csc.py:150
+        if isinstance(a, slice) and isinstance(b, slice):
+            return self                                                                # csc.py:180-182
+        if isinstance(a, slice):                         # (:, b) / (:, list_b): whole columns
+            cols = as_idx(b)
+            Bp, Bi, Bx = _sub_matrix_cols(self.indptr, self.indices, self.data, cols)
+            return CscMat(self.m, len(cols), indptr=Bp, indices=Bi, data=Bx)
+        if not (is_int(a) or isinstance(a, Iterable)) or not (is_int(b) or isinstance(b, slice) or isinstance(b, Iterable)):
+            raise Exception('The indices must be a tuple :/')
+        rows = as_idx(a)
+        cols = np.arange(self.n, dtype=np.int32) if isinstance(b, slice) else as_idx(b)      # (a, :) / (list_a, :): every column
+        _, Bp, Bi, Bx = _k.csc_sub_matrix(self.m, self.nzmax, self.indptr, self.indices, self.data, rows, cols)
+        return CscMat(len(rows), len(cols), indptr=Bp, indices=Bi, data=Bx)
+
+    def __setitem__(self, key, value):
+        raise Exception('Setting values is not allowed in a CSC Matrix, use a Lil Matrix instead and convert it to CSC')
+
+    def _add(self, other, beta):
+        if isinstance(other, CscMat):
+            assert other.m == self.m                     # csc.py:309-310
+            assert other.n == self.n
+            m, n, Cp, Ci, Cx = _k.csc_add_ff(self.m, self.n, self.indptr, self.indices, self.data,
+                                             other.m, other.n, other.indptr, other.indices, other.data, 1.0, beta)
+            return CscMat(m, n, indptr=Cp, indices=Ci, data=Cx)
+        if isinstance(other, (float, int)):
+            raise NotImplementedError('Adding a nonzero scalar to a sparse matrix would make it a dense matrix.')
+        raise NotImplementedError('Type not supported')
+
+    def __add__(self, other):
+        """A + B on the device through the package's own kernel csc_add_ff (csc_numba.py:183-219: entries in its order,
+        explicit zeros kept); the reference's operator goes through SciPy's csc_plus_csc (csc.py:301-322) -- the dense
+        results are equal, which is what its test compares (src/test/test1_operations.py:12-72)."""
+        return self._add(other, 1.0)
+
+    def __sub__(self, other):
+        return self._add(other, -1.0)
+
+    def __neg__(self):
+        return self.__mul__(-1.0)                        # csc.py:425-430
+
+    def __eq__(self, other):
+        """Same shape and the same three arrays, entry by entry (csc.py:432-457)."""
+        if not isinstance(other, CscMat) or self.shape != other.shape:
+            return False
+        same = lambda x, y: all(p == q for p, q in zip(x, y))
+        return bool(same(self.indices, other.indices) and same(self.indptr, other.indptr) and same(self.data, other.data))
+
+    __hash__ = None
+
     def __mul__(self, other):
         """A * x for a vector or an [n, k] block, on the device (csc.py:372-415 semantics)."""
         if isinstance(other, np.ndarray):
@@ -129,6 +192,19 @@ class CscMat:
     def solve(self, b, tol=0.0):
         """x = A \\ b by LU (factorises if needed)."""
         return self.lu(tol).solve(b)
+
+
+def _sub_matrix_cols(Ap, Ai, Ax, cols):
+    """Whole columns `cols` of a CSC matrix with their original row indices (csc_sub_matrix_cols, csc_numba.py:505-538):
+    a copy of contiguous slices, done on the host where the arrays live."""
+    counts = np.asarray([Ap[j + 1] - Ap[j] for j in cols], dtype=np.int64)
+    Bp = np.zeros(len(cols) + 1, dtype=np.int32)
+    Bp[1:] = np.cumsum(counts)
+    if len(cols):
+        take = np.concatenate([np.arange(Ap[j], Ap[j + 1]) for j in cols]) if counts.sum() else np.zeros(0, dtype=np.int64)
+    else:
+        take = np.zeros(0, dtype=np.int64)
+    return Bp, np.asarray(Ai)[take].astype(np.int32), np.asarray(Ax)[take].astype(np.float64)
 
 
 def scipy_to_mat(scipy_mat):

@@ -22,6 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CS3_LIB_PATH") or os.path.join(_HERE, "libcsparse3_hip.so")   # (override: sanitizer builds, tools/asan_host.sh)
 
 CS3_LU, CS3_CHOLESKY = 0, 1
+CS3_ERR_ARG, CS3_ERR_ALLOC, CS3_ERR_HIP, CS3_ERR_PIVOT, CS3_ERR_NOT_SPD, CS3_ERR_STATE = -1, -2, -3, -4, -5, -6      # include/csparse3_amd.h
 ORDER_NATURAL, ORDER_AMD, ORDER_GIVEN = 0, 1, 2
 
 _i32p = C.POINTER(C.c_int32)

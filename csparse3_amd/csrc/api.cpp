@@ -288,6 +288,7 @@ int run_factor(cs3_handle h, const double *ax_dev, double tol, hipStream_t st)
     CS3_HIP(launch_prologue(D, ax_dev, nullptr, 0, st));        // status 0x7f7f7f7f = clean, zeros, values
     if (h->use_graph) {
         if (h->factor_graph && h->factor_graph_inv_tol != inv_tol) {
+            CS3_HIP(hipDeviceSynchronize());                    // (a launch of it on another stream may still be running)
             (void) hipGraphExecDestroy(h->factor_graph);
             h->factor_graph = nullptr;
         }
@@ -312,10 +313,14 @@ int read_status(cs3_handle h, hipStream_t st)
     int word[4] = {0, 0, 0, 0};
     CS3_HIP(hipMemcpyAsync(word, h->D.status, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
     CS3_HIP(hipStreamSynchronize(st));
-    if (word[3] != 0) {               // a hand-over of the fused step timed out (k_flag_wait): its sweep ran unsynchronised
+    if (word[3] != 0) {
+        // a wait inside the step was given up: a wave of a shared elimination never saw the multipliers of its partner
+        // (eliminate_pair / eliminate_parts / the shared fronts of the forest), or the side queue of the fused step its
+        // release (k_flag_wait, CS3_FLAG_SYNC=1).  Whatever was computed behind that point is not to be used.
         CS3_HIP(hipMemsetAsync(h->D.status + 3, 0, sizeof(int), st));
         h->factored = false;
-        set_error("fused factor + solve: the side queue gave up waiting for the factorisation (CS3_FLAG_SYNC=1 needs concurrent queues: unset it under tools that serialise kernels)");
+        set_error("a hand-over inside the step timed out (waves of a shared elimination, or the side queue of the fused step under "
+                  "CS3_FLAG_SYNC=1, which needs concurrent queues): the factors and solutions of this step are not valid");
         return CS3_ERR_STATE;
     }
     const int col = word[0];
@@ -348,6 +353,7 @@ int run_solve(cs3_handle h, double *x_dev, long long k, int mode, hipStream_t st
         h->inverses_valid = true;
     }
     D.xm = XMap();
+    struct XmReset { DeviceFactor &D; ~XmReset() { D.xm = XMap(); } } xm_reset{D};    // (also on every error return below)
     if (mode == 0 && permutation_can_fuse(D, nrhs)) {
         // the permutations ride on the sweeps: the forward sweep reads row q[k] of the caller's X, the backward sweep
         // writes the solution rows back there; X's address is baked into the graph, so graphs are kept per (nrhs, X)
@@ -357,7 +363,7 @@ int run_solve(cs3_handle h, double *x_dev, long long k, int mode, hipStream_t st
             auto it = h->solve_graphs_px.find(key);
             if (it == h->solve_graphs_px.end()) {
                 if (h->solve_graphs_px.size() >= 8) {           // callers that rotate buffers: bounded cache
-                    CS3_HIP(hipStreamSynchronize(st));
+                    CS3_HIP(hipDeviceSynchronize());            // (graphs launched earlier on OTHER streams may still be running)
                     for (auto &kv : h->solve_graphs_px) (void) hipGraphExecDestroy(kv.second);
                     h->solve_graphs_px.clear();
                 }
@@ -411,12 +417,14 @@ int run_factor_solve(cs3_handle h, const double *ax_dev, const double *b_dev, do
     DeviceFactor &D = h->D;
     const int nrhs = (int) k;
     const double inv_tol = (tol > 0.0) ? 1.0 / tol : HUGE_VAL;
+    D.xm = XMap();                                              // (never a caller's pointer left over from a failed solve)
     const std::vector<LaunchGroup> &sg = select_sweep_schedule(h, nrhs);
     D.fwd_in_factor = nrhs == 1 && !h->S.sub_tiers.empty();   // the tiers' factor launches carry their forward sweep
     D.inverses_in_sweep = true;                                // captured with the graph: the forward sweep inverts group by group
     CS3_HIP(launch_prologue(D, ax_dev, b_dev, nrhs, st));      // right-hand sides are read from b_dev, the solution goes to x_dev
     if (h->use_graph) {
         if (h->fused_inv_tol != inv_tol) {
+            if (!h->fused_graphs.empty() || !h->fused_graphs_px.empty()) CS3_HIP(hipDeviceSynchronize());   // they may still be running
             for (auto &kv : h->fused_graphs) (void) hipGraphExecDestroy(kv.second);
             h->fused_graphs.clear();
             for (auto &kv : h->fused_graphs_px) (void) hipGraphExecDestroy(kv.second);
@@ -430,7 +438,7 @@ int run_factor_solve(cs3_handle h, const double *ax_dev, const double *b_dev, do
             auto px = h->fused_graphs_px.find(key);
             if (px == h->fused_graphs_px.end()) {
                 if (h->fused_graphs_px.size() >= 4) {
-                    CS3_HIP(hipStreamSynchronize(st));
+                    CS3_HIP(hipDeviceSynchronize());            // (see solve_graphs_px)
                     for (auto &kv : h->fused_graphs_px) (void) hipGraphExecDestroy(kv.second);
                     h->fused_graphs_px.clear();
                 }
@@ -793,6 +801,15 @@ int64_t cs3_debug_forest(cs3_handle h, int32_t *supernode, int32_t *task, int32_
         }
     }
     return (int64_t) S.sub_sn.size();
+}
+
+int cs3_debug_withhold_handover(int on)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("cs3_debug_withhold_handover: no HIP device"); return CS3_ERR_HIP; }
+    CS3_HIP(hipDeviceSynchronize());
+    CS3_HIP(set_withhold_handover(on ? 1 : 0));
+    return CS3_OK;
 }
 
 int cs3_debug_front_stamps(cs3_handle h, int64_t *out)

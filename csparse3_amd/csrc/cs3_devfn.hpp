@@ -45,5 +45,38 @@ __device__ __forceinline__ void flag_column(int *status, int col)
     atomicMin(status, col);
 }
 
+// ---- multipliers handed from wave to wave through LDS (eliminate_pair / eliminate_parts, the shared fronts of forest.hip) --
+// The producer stores a vector of multipliers, then the number of pivots handed over so far; the consumer polls that number.
+// LDS operations of one wave complete in order, so no fence sits on the producer's pivot chain (a release fence per pivot
+// measured 350 instead of 275 cycles per pivot); the counter is accessed with relaxed workgroup-scope atomics so that the
+// contract with the compiler is explicit, the multipliers through volatile LDS pointers.
+typedef volatile __attribute__((address_space(3))) double *lds_vdouble_ptr;
+typedef __attribute__((address_space(3))) int *lds_int_ptr;
+
+// CS3_DEBUG_WITHHOLD=1 (cs3_debug_withhold_handover): producers keep their counters back, so that every consumer runs
+// into its time-out -- the test of the give-up path.  One copy per translation unit (no relocatable device code in this
+// build): kernels.hip and forest.hip each export a setter.
+static __device__ int g_withhold_handover = 0;
+
+__device__ __forceinline__ void handover_publish(lds_int_ptr ready, int value, bool withhold)
+{
+    if (!withhold) __hip_atomic_store(ready, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Waits until the counter exceeds `need`; false when the wait was given up.  A consumer that gives up raises status[3]:
+// cs3_factor_status then reports the step as failed (CS3_ERR_STATE) instead of letting a wrong factor pass.
+__device__ __forceinline__ bool handover_wait(lds_int_ptr ready, int need, int *status, bool withhold)
+{
+    const int limit = withhold ? (1 << 8) : (1 << 22);
+    for (int it = 0; __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= need; ++it) {
+        if (it >= limit) {
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(status + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return true;
+}
+
 
 }  // namespace cs3

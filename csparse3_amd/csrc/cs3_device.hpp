@@ -140,6 +140,8 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
 hipError_t launch_prologue(const DeviceFactor &D, const double *ax_src, const double *x_src, int nrhs, hipStream_t st);
 // forest.hip: one tier of the bottom forest = one launch, one workgroup per task
 hipError_t prepare_forest_kernels();
+hipError_t set_withhold_handover(int on);          // diagnostics: producers of the LDS hand-overs keep their counters back
+hipError_t set_withhold_handover_forest(int on);   //   (the copy of the flag in forest.hip)
 hipError_t launch_sub_factor(const DeviceFactor &D, int tier, bool with_forward, double inv_tol, hipStream_t st);
 hipError_t launch_sub_sweep(const DeviceFactor &D, int tier, double *X, bool forward, hipStream_t st);
 hipError_t launch_permute(const DeviceFactor &D, const double *src, double *dst, int nrhs, bool scatter,

@@ -240,8 +240,7 @@ __device__ __forceinline__ void coop_extend_add(double *S, int ld, int sdummy, i
 // it).  Pivots and multipliers are checked afterwards, off this chain.
 template <bool RHS, int PART>
 __device__ __forceinline__ void coop_own_pivots_lu(double (&d)[COOP_NC], double &rhs, int w, bool last,
-                                                   volatile __attribute__((address_space(3))) double *lm,
-                                                   volatile __attribute__((address_space(3))) int *ready, int gbase)
+                                                   lds_vdouble_ptr lm, lds_int_ptr ready, int gbase, bool withhold)
 {
     constexpr int NC = COOP_NC, pc0 = NC * PART;
     const int lane = threadIdx.x & 63;
@@ -254,7 +253,7 @@ __device__ __forceinline__ void coop_own_pivots_lu(double (&d)[COOP_NC], double 
             d[k] *= rp;                                         // the multipliers
             if (!last) {
                 lm[k * 64 + lane] = d[k];
-                if (lane == 63) *ready = gbase + pl + 1;
+                if (lane == 63) handover_publish(ready, gbase + pl + 1, withhold);
             }
             if (k + 1 < NC) {
                 d[k + 1] -= d[k] * bcast_lane(d[k + 1], pl);
@@ -357,7 +356,8 @@ sub_coop_front(const SubScalars &ds, int part, double *gimg, int img_stride, int
         if (RHS) rhs = S[li + NC * ld];
     }
     // (explicitly LDS: through generic pointers the hand-over becomes flat accesses)
-    auto *ready = (volatile __attribute__((address_space(3))) int *) ready_generic;
+    auto ready = (lds_int_ptr) ready_generic;
+    const bool withhold = g_withhold_handover != 0;
     bool suspect = false;
     // ---- the pivots to my left, as they appear.  The counter is read once per batch: a part that lags (every part
     // does: applying a pivot costs more than producing it on eight columns) then applies what is there, four pivots per
@@ -394,13 +394,16 @@ sub_coop_front(const SubScalars &ds, int part, double *gimg, int img_stride, int
                 rhs -= l * bcast_lane(rhs, g);
             }
         };
-        auto *lm0 = (volatile __attribute__((address_space(3))) double *) (gimg + COOP_SLICE);
+        auto lm0 = (lds_vdouble_ptr) (gimg + COOP_SLICE);
         auto lm_at = [&](int g) -> double { return lm0[(g >> 3) * img_stride + (g & 7) * 64 + lane]; };
         int g = 0, spins = 0;
         while (g < nleft) {
-            const int upto = min(uni(*ready) - gbase, nleft);
+            const int upto = min(uni(__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - gbase, nleft);
             if (upto <= g) {
-                if (++spins > (1 << 22)) { if (lane == 0) status[3] = 1; break; }   // gave up: cs3_factor_status reports the step as failed
+                if (++spins > (withhold ? (1 << 8) : (1 << 22))) {      // gave up: cs3_factor_status reports the step as failed
+                    if (lane == 0) __hip_atomic_store(status + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(1);
                 continue;
             }
@@ -413,14 +416,14 @@ sub_coop_front(const SubScalars &ds, int part, double *gimg, int img_stride, int
     }
     // ---- my own pivots
     if (pc0 < w) {
-        auto *lm = (volatile __attribute__((address_space(3))) double *) (S + COOP_SLICE);
+        auto lm = (lds_vdouble_ptr) (S + COOP_SLICE);
         if (KIND == CS3_LU) {
             // (the part number as a compile-time constant: the pivot's lane is then an immediate of the lane-to-scalar reads)
             switch (part) {
-            case 0: coop_own_pivots_lu<RHS, 0>(d, rhs, w, last, lm, ready, gbase); break;
-            case 1: coop_own_pivots_lu<RHS, 1>(d, rhs, w, last, lm, ready, gbase); break;
-            case 2: coop_own_pivots_lu<RHS, 2>(d, rhs, w, last, lm, ready, gbase); break;
-            default: coop_own_pivots_lu<RHS, 3>(d, rhs, w, last, lm, ready, gbase); break;
+            case 0: coop_own_pivots_lu<RHS, 0>(d, rhs, w, last, lm, ready, gbase, withhold); break;
+            case 1: coop_own_pivots_lu<RHS, 1>(d, rhs, w, last, lm, ready, gbase, withhold); break;
+            case 2: coop_own_pivots_lu<RHS, 2>(d, rhs, w, last, lm, ready, gbase, withhold); break;
+            default: coop_own_pivots_lu<RHS, 3>(d, rhs, w, last, lm, ready, gbase, withhold); break;
             }
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
@@ -453,7 +456,7 @@ sub_coop_front(const SubScalars &ds, int part, double *gimg, int img_stride, int
                 }
                 if (!last) {
                     lm[k * 64 + lane] = (lane == pl) ? rpk : l;
-                    if (lane == 0) *ready = gbase + pl + 1;
+                    if (lane == 0) handover_publish(ready, gbase + pl + 1, withhold);
                 }
                 if (RHS && last) {
                     if (lane == pl) rhs *= rpk;
@@ -922,6 +925,11 @@ k_sub_bwd(const SubTask *__restrict__ tasks, int task0, const SubFront *__restri
 
 // --------------------------------------------------------------- launchers --
 #define CS3_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t set_withhold_handover_forest(int on)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_withhold_handover), &on, sizeof(int));
+}
 
 hipError_t prepare_forest_kernels()
 {

@@ -28,6 +28,12 @@
 
 namespace cs3 {
 
+hipError_t set_withhold_handover(int on)         // diagnostics: see handover_publish (cs3_devfn.hpp)
+{
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_withhold_handover), &on, sizeof(int));
+    return e != hipSuccess ? e : set_withhold_handover_forest(on);
+}
+
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // ----------------------------------------------------- assembly by gather --
@@ -347,28 +353,30 @@ __device__ __forceinline__ void eliminate_slice(double (&d)[NC], int c0, bool ke
 // 16..31.  Wave 0 eliminates its 16 pivots and hands the multipliers of each to wave 1 through LDS (lm[k][lane], then
 // *ready = k + 1: LDS operations of a wave complete in order); wave 1 applies them to its columns one pivot behind,
 // then eliminates pivots 16..31 alone.  Wave 0 never waits for wave 1, so the wait below cannot deadlock; it is bounded
-// anyway (a wave that gives up produces a wrong factor, which the residual checks catch, not a hung GPU).
+// anyway, and a wave that gives up raises status[3]: cs3_factor_status reports the step as failed (handover_wait).
 template <int KIND>
-__device__ __forceinline__ void eliminate_pair(double (&d)[PAIR_NC], int part, bool keep_unscaled, double *lm_generic, volatile int *ready_generic,
-                                               int npiv = 1 << 30)
+__device__ __forceinline__ void eliminate_pair(double (&d)[PAIR_NC], int part, bool keep_unscaled, double *lm_generic, int *ready_generic,
+                                               int *status, int npiv = 1 << 30)
 {
     constexpr int NC = PAIR_NC;
     const int lane = threadIdx.x & 63;
     // (explicitly LDS: through generic pointers these become flat accesses, and every hand-over waits out a flat store)
     // volatile on both sides instead of fences: the compiler keeps volatile accesses in program order, the LDS performs a
     // wave's operations in order -- a release fence after every hand-over (s_waitcnt lgkmcnt(0)) sat on the pivot chain
-    auto *lm = (volatile __attribute__((address_space(3))) double *) lm_generic;
-    auto *ready = (volatile __attribute__((address_space(3))) int *) ready_generic;
+    auto lm = (lds_vdouble_ptr) lm_generic;
+    auto ready = (lds_int_ptr) ready_generic;
+    const bool withhold = g_withhold_handover != 0;
     if (part == 0) {
         eliminate_slice<KIND, NC>(d, 0, keep_unscaled, [&](int k, double l) {
             lm[k * 64 + lane] = l;
-            if (lane == 0) *ready = k + 1;
+            if (lane == 0) handover_publish(ready, k + 1, withhold);
         }, npiv);
         return;
     }
+    bool alive = true;                                          // (a consumer that gave up once does not wait again)
 #pragma unroll
     for (int k = 0; k < NC; ++k) {                              // (all NC hand-overs happen, with zeros past npiv)
-        for (int it = 0; *ready <= k && it < (1 << 20); ++it) __builtin_amdgcn_s_sleep(1);
+        if (alive) alive = handover_wait(ready, k, status, withhold);
         const double l = lm[k * 64 + lane];                     // zero on and above the pivot row
 #pragma unroll
         for (int j0 = 0; j0 < NC; j0 += 8) {
@@ -391,12 +399,14 @@ __device__ __forceinline__ void eliminate_pair(double (&d)[PAIR_NC], int part, b
 // all producers), then eliminates its own pivots and publishes them.  Only pivots < npiv exist; wave 0 publishes all 16
 // of its steps (zeros past npiv) so that it runs without a branch, the others publish the real ones only.
 template <int KIND>
-__device__ __forceinline__ void eliminate_parts(double (&d)[PAIR_NC], int part, int nparts, double *lm_generic, int *ready_generic, int npiv)
+__device__ __forceinline__ void eliminate_parts(double (&d)[PAIR_NC], int part, int nparts, double *lm_generic, int *ready_generic, int npiv, int *status)
 {
     constexpr int NC = PAIR_NC;
     const int lane = threadIdx.x & 63;
-    auto *lm = (volatile __attribute__((address_space(3))) double *) lm_generic;
-    auto *ready = (volatile __attribute__((address_space(3))) int *) ready_generic;
+    auto lm = (lds_vdouble_ptr) lm_generic;
+    auto ready = (lds_int_ptr) ready_generic;
+    const bool withhold = g_withhold_handover != 0;
+    bool alive = true;
     const int c0 = NC * part;
     // blocks of 16 pivots to my left, whole blocks only (one branch per block, none per pivot: a block that holds a real
     // pivot was published in full, with zero multipliers past npiv)
@@ -404,7 +414,7 @@ __device__ __forceinline__ void eliminate_parts(double (&d)[PAIR_NC], int part, 
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
             const int g = g0 + k;
-            for (int it = 0; *ready <= g && it < (1 << 20); ++it) __builtin_amdgcn_s_sleep(1);
+            if (alive) alive = handover_wait(ready, g, status, withhold);
             const double l = lm[g * 64 + lane];                 // zero on and above the pivot row
 #pragma unroll
             for (int j0 = 0; j0 < NC; j0 += 8) {
@@ -422,7 +432,7 @@ __device__ __forceinline__ void eliminate_parts(double (&d)[PAIR_NC], int part, 
     if (c0 >= npiv) return;                                     // no pivot of mine exists
     auto publish = [&](int k, double l) {
         lm[(c0 + k) * 64 + lane] = l;
-        if (lane == 0) *ready = c0 + k + 1;
+        if (lane == 0) handover_publish(ready, c0 + k + 1, withhold);
     };
     // a wave with consumers to its right runs all 16 steps without a branch; the last one skips the steps past npiv
     if (part + 1 < nparts) eliminate_slice<KIND, NC, false>(d, c0, false, publish, npiv);
@@ -487,7 +497,7 @@ front_wave_body(const FrontDesc &d, int first, double *F,
                 hrow[j] = (lane < r && c0 + j < r) ? v : 0.0;
             }
             CS3_STAMP(3);
-            eliminate_parts<KIND>(hrow, part, (r + PAIR_NC - 1) / PAIR_NC, lm, ready, w);
+            eliminate_parts<KIND>(hrow, part, (r + PAIR_NC - 1) / PAIR_NC, lm, ready, w, status);
             CS3_STAMP(4);
             if (live) {
 #pragma unroll
@@ -1280,7 +1290,7 @@ k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__res
         const double tv = T[32 * half + li][cbase + j];
         e[j] = stacked ? (diag_tile ? 0.0 : tv) : dv;
     }
-    eliminate_pair<KIND>(e, part, row_tile, (half == 0) ? &As[0][0] : &Bs[0][0], &pair_ready[half]);
+    eliminate_pair<KIND>(e, part, row_tile, (half == 0) ? &As[0][0] : &Bs[0][0], &pair_ready[half], status);
     CS3_BSTAMP(4);
     CS3_BSTAMP_ROW(6);
     if (diag_tile) {                                // park the factored block, check its pivots

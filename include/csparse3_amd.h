@@ -170,6 +170,10 @@ int cs3_debug_front_stamps(cs3_handle h, int64_t *out);
 /* Fills the LDS of every CU with NaN bit patterns (the LDS keeps its contents between kernels): the parity tests call it
  * before the numeric entry points so that a product of a masked zero and an unwritten LDS word cannot hide. */
 int cs3_debug_poison_lds(void *stream);
+/* on != 0: the producers of the LDS hand-overs between waves (shared eliminations) keep their counters back, so every
+ * consumer runs into its bounded wait and gives up: the step must then be reported as failed by cs3_factor_status
+ * (CS3_ERR_STATE), never pass silently.  Process-wide; on = 0 restores the normal path.  For the test of that path. */
+int cs3_debug_withhold_handover(int on);
 /* Factorisation schedule: supernode id, front order r and width w per schedule slot. */
 int cs3_debug_schedule(cs3_handle h, int32_t *sched, int32_t *front_r, int32_t *front_w);
 /* The bottom forest (subtrees of small fronts walked by one workgroup each): returns the number of forest

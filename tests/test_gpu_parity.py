@@ -956,3 +956,38 @@ def test_distinct_patterns_one_matrix_per_stream(gpu, orc):
         A = csc_to_scipy(m, n, Ap, Ai, Ax)
         assert np.abs(A @ X[i] - B[i]).max() <= 1e-11 * n
     assert rel_err(X[5], orc.csc_cholsol_f(1, mats[5][1], mats[5][2], mats[5][3], mats[5][4], B[5])) <= RTOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("diag_scale", [0.1, 0.005])
+def test_inverse_based_sweeps_hold_up_with_large_multipliers(gpu, diag_scale):
+    """With 16 or more right-hand sides the fronts of order > 32 are swept with explicit inverses of their 64 x 64 diagonal
+    blocks (k_inv_diag / k_gemm_fwd / k_gemm_bwd), which is not backward stable in general; every other many-RHS test is
+    diagonally dominant (multipliers << 1).  Here the diagonal is weak: multipliers reach ~200 (tol = 1e-3 admits 1000) and
+    the residual of the substitution path itself grows to 1e-15 .. 1e-12.  The same b goes through the one-RHS substitution
+    sweeps and as the columns of a 32-column block through the inverse-based ones: the block's residual must stay within a
+    small factor of the substitution path's, column for column.  (kernels.hip:2722; measured equal.)"""
+    import scipy.sparse as sp
+    hip = gpu
+    m, n, Ap, Ai, Ax = synth.dense_block_matrix(500, 260, seed=5)
+    A = sp.csc_matrix((Ax, Ai, Ap), shape=(n, n)).tolil()
+    A.setdiag(A.diagonal() * diag_scale)
+    A = A.tocsc(); A.sort_indices()
+    Ap2, Ai2, Ax2 = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy()
+    rng = np.random.default_rng(0)
+    B = rng.standard_normal((n, 32))
+    with hip.Factorization(n, n, Ap2, Ai2) as F:
+        F.factor(Ax2, 1e-3)
+        Lx = F.factors()[2]
+        assert np.abs(Lx).max() > 50.0, "the case is meant to have large multipliers"
+        assert F.info.max_front > 64
+        X1 = np.stack([F.solve(B[:, j].copy()) for j in range(4)], axis=1)      # substitution sweeps, one column at a time
+        X = F.solve(B.copy())                                                   # inverse-based GEMM sweeps
+    scale = np.abs(A).max()
+    res = lambda x, b: np.abs(A @ x - b).max() / (scale * np.abs(x).max() + np.abs(b).max())
+    for j in range(4):
+        r1, rk = res(X1[:, j], B[:, j]), res(X[:, j], B[:, j])
+        assert rk <= 8.0 * r1 + 1e-14, (j, r1, rk)
+        assert np.abs(X[:, j] - X1[:, j]).max() <= 1e-9 * np.abs(X1[:, j]).max()
+    for j in range(4, 32):
+        assert res(X[:, j], B[:, j]) <= 1e-10

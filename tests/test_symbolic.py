@@ -180,6 +180,33 @@ def test_amd_fill_quality(hip):
         assert nnz_l < int(F.info.nnz_l)                  # and it beats no ordering at all
 
 
+@pytest.mark.parametrize("which", ["config3_jacobian_50k", "config5_spd_5k"])
+def test_amd_quality_gate_at_the_configurations_own_sizes(hip, which):
+    """The same oracle-independent gate at the sizes BASELINE.json quotes: cs3_amd returns a
+    permutation, the same one on a second run, and its fill stays within 5 % of SuperLU's MMD_AT_PLUS_A on the same
+    pattern (the 50 000-column Jacobian of configs[2..3], the 5 000-column SPD pattern of configs[4])."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    if which == "config3_jacobian_50k":
+        m, n, Ap, Ai, Ax = CASES["grid50k"]
+        kind = hip.CS3_LU
+    else:
+        ei, ej = synth.spd_grid_pattern(5000, seed=5000)
+        m, n, Ap, Ai, Ax = synth.spd_grid_matrix(5000, ei, ej, seed=5000)
+        kind = hip.CS3_CHOLESKY
+    q = hip.csc_amd_f(1, m, n, Ap, Ai)
+    assert np.array_equal(np.sort(q), np.arange(n)), "not a permutation"
+    assert np.array_equal(q, hip.csc_amd_f(1, m, n, Ap, Ai)), "two runs, two orders"
+    with hip.Factorization(m, n, Ap, Ai, kind=kind) as F:
+        nnz_l = int(F.info.nnz_l)
+        assert np.array_equal(F.ordering()["q_amd"], q)
+    A = sp.csc_matrix((Ax, Ai, Ap), shape=(n, n))
+    if kind == hip.CS3_CHOLESKY:                     # one triangle is stored: SuperLU gets the full symmetric matrix
+        A = (A + A.T - sp.diags(A.diagonal())).tocsc()
+    lu = spl.splu(A, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+    assert nnz_l <= 1.05 * lu.L.nnz, "AMD fill %d vs SuperLU MMD_AT_PLUS_A %d" % (nnz_l, lu.L.nnz)
+
+
 def test_cscmat_reanalyses_when_the_pattern_changes(hip):
     """CscMat caches its symbolic analysis; the cache key includes a digest of indptr / indices, so changing
     the pattern in place (or reassigning the arrays) between two factorisations cannot reuse a stale one."""

@@ -116,7 +116,7 @@ SolveDesc solve_desc_of(const Symbolic &S, i32 s)
     f.bv = S.bv_off[s];
     f.gv = S.gv_off[s]; f.dinv = S.dinv_off[s];
     f.rl_begin = S.rl_ptr[s]; f.rl_count = (int) (S.rl_ptr[s + 1] - S.rl_ptr[s]);
-    if (S.sn_class[s] != FC_IL && !S.sn_il_panels[s]) { f.rl_begin = S.sl_ptr[s]; f.rl_count = S.sl_rounds[s]; }   // not a lane = matrix sweep
+    if (S.sn_class[s] != FC_IL) { f.rl_begin = S.sl_ptr[s]; f.rl_count = S.sl_rounds[s]; }   // not a lane = matrix sweep
     f.c0 = S.sn_ptr[s];
     f.r = (int) (S.st_ptr[s + 1] - S.st_ptr[s]);
     f.w = S.sn_ptr[s + 1] - S.sn_ptr[s];
@@ -218,7 +218,7 @@ int ensure_device_impl(cs3_handle h)
     D.pool_pm = D.pool + il_doubles - D.il_len;            // virtual offsets >= il_len index this pointer directly
     CS3_HIP(hipMalloc((void **) &D.dbuf, std::max<size_t>(1, (size_t) (D.batch * D.dbuf_size)) * sizeof(double)));
     CS3_HIP(hipMalloc((void **) &D.ax, std::max<size_t>(1, (size_t) (D.batch * D.nnz_a)) * sizeof(double)));
-    CS3_HIP(hipMalloc((void **) &D.status, 4 * sizeof(int)));    // [0] the status word, [1], [2] hand-over words of the fused step (k_flag_wait)
+    CS3_HIP(hipMalloc((void **) &D.status, 4 * sizeof(int)));    // [0] the status word, [1], [2] unused, [3] a hand-over between waves timed out
     CS3_HIP(hipMemset(D.status, 0, 4 * sizeof(int)));
     CS3_HIP(hipMemset(D.status, 0x7f, sizeof(int)));      // "clean": a handle that only imports factors never runs a prologue
     if (const char *pf = std::getenv("CS3_PROFILE")) {
@@ -315,12 +315,11 @@ int read_status(cs3_handle h, hipStream_t st)
     CS3_HIP(hipStreamSynchronize(st));
     if (word[3] != 0) {
         // a wait inside the step was given up: a wave of a shared elimination never saw the multipliers of its partner
-        // (eliminate_pair / eliminate_parts / the shared fronts of the forest), or the side queue of the fused step its
-        // release (k_flag_wait, CS3_FLAG_SYNC=1).  Whatever was computed behind that point is not to be used.
+        // (eliminate_pair / eliminate_parts / the shared fronts of the forest).  Whatever was computed behind that point
+        // is not to be used.
         CS3_HIP(hipMemsetAsync(h->D.status + 3, 0, sizeof(int), st));
         h->factored = false;
-        set_error("a hand-over inside the step timed out (waves of a shared elimination, or the side queue of the fused step under "
-                  "CS3_FLAG_SYNC=1, which needs concurrent queues): the factors and solutions of this step are not valid");
+        set_error("a hand-over between the waves of a shared elimination timed out: the factors and solutions of this step are not valid");
         return CS3_ERR_STATE;
     }
     const int col = word[0];

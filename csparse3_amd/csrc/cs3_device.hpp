@@ -98,7 +98,7 @@ struct DeviceFactor {
     bool inverses_in_sweep = false;   // the forward sweep computes them group by group (fused factor + solve graph)
     XMap xm;                          // what the sweeps captured / launched next should use (set by the caller)
     long long nrhs_cap = 0;
-    int *status = nullptr;        // [0] first failing pivot column, 0x7f7f7f7f when clean; [1], [2]: hand-over words of the fused step
+    int *status = nullptr;        // [0] first failing pivot column, 0x7f7f7f7f when clean; [3]: a hand-over between waves timed out
     long long *tbuf = nullptr;    // diagnostics (CS3_PROFILE=1): 8 shader-clock stamps per front, schedule order
 };
 

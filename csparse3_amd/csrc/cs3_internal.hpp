@@ -110,7 +110,6 @@ struct Symbolic {
     // supernodes
     i32 nsuper = 0;
     std::vector<i32> sn_ptr, col2sn, sn_parent, sn_level, sn_class;
-    std::vector<i32> sn_il_panels;            // 1: a lane = row front whose panels live in the interleaved region (symbolic.cpp)
     std::vector<i64> st_ptr;                  // [nsuper+1] into st_idx
     std::vector<i32> st_idx;                  // sorted row structure; first w entries = own columns
     std::vector<i32> child_ptr, child_idx;    // children of each supernode, ascending

@@ -648,12 +648,12 @@ __global__ void __launch_bounds__(256)
 k_front_mix(const FrontDesc *__restrict__ fdesc, int first,
             const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
             const double *__restrict__ ax_all, double *__restrict__ pool_all,
-            long long nnz_a, long long pool_stride, IlView il, double inv_tol, int *status, long long *tbuf, int lds_grid)
+            long long nnz_a, long long pool_stride, IlView il, double inv_tol, int *status, long long *tbuf)
 {
     extern __shared__ __attribute__((aligned(16))) double F[];
     const long long t_start = tbuf ? (long long) __builtin_amdgcn_s_memtime() : 0;
     const FrontDesc d = fdesc[first + blockIdx.x];
-    if (!lds_grid || d.r <= 32)         // (four waves: the cooperative path of front_wave_body serves every order <= 64)
+    if (d.r <= 32)                      // (four waves gather, two share the elimination)
         front_wave_body<KIND, 32>(d, first, F, asm_src, asm_tgt, long_src, ax_all, pool_all, nnz_a, pool_stride, il,
                                   inv_tol, status, tbuf, t_start);
     else
@@ -673,11 +673,8 @@ __global__ void __launch_bounds__(256)
 k_big_gather(const FrontDesc *__restrict__ fdesc, int first,
              const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
              const double *__restrict__ ax_all, double *__restrict__ pool_all,
-             long long nnz_a, long long pool_stride, IlView il, int *signal)
+             long long nnz_a, long long pool_stride, IlView il)
 {
-    // (fused step: everything launched before this kernel on its stream is complete -- tell the side queue, k_flag_wait)
-    if (signal && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
-        __hip_atomic_store(signal, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     const FrontDesc d = fdesc[first + blockIdx.z];
     const double *pil = il_lane_base(il, blockIdx.y);
     const double *ax = ax_all + (long long) blockIdx.y * nnz_a;
@@ -1124,10 +1121,8 @@ template <int KIND>
 __global__ void __launch_bounds__(256)
 k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__restrict__ pool_all,
            long long pool_stride, double *__restrict__ dbuf_all, long long dbuf_stride,
-           double inv_tol, int *status, int batch, long long *tbuf, int *signal)
+           double inv_tol, int *status, int batch, long long *tbuf)
 {
-    if (signal && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)      // (see k_big_gather)
-        __hip_atomic_store(signal, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     // diagnostics (CS3_PROFILE=1): block-column tile (1, 0) of the step kb == 64 stamps its phases into the front's slot
     const long long t_start = tbuf ? (long long) __builtin_amdgcn_s_memtime() : 0;
 #define CS3_BSTAMP(p) do { if (tbuf && kb == 64 && blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0) \
@@ -3302,18 +3297,18 @@ static int grid_for(long long work, int block, int cap = 4096)
 // A group of big fronts = one gather launch, then launches 0 .. nblk of the block step (nblk = closing).
 static int big_group_blocks(const LaunchGroup &g) { return (g.max_w + BIG_NB - 1) / BIG_NB; }
 
-static hipError_t launch_big_gather(const DeviceFactor &D, const LaunchGroup &g, hipStream_t st, int *signal = nullptr)
+static hipError_t launch_big_gather(const DeviceFactor &D, const LaunchGroup &g, hipStream_t st)
 {
     const int chunks = (int) (g.max_asm >> 6);
     const int gx = std::max(1, std::min(64, (chunks + 4 * GATHER_UNROLL - 1) / (4 * GATHER_UNROLL)));
     hipLaunchKernelGGL(k_big_gather, dim3(gx, (unsigned) D.batch, g.count), dim3(256), 0, st, D.fdesc, g.first,
-                       D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool_pm, D.nnz_a, D.pm_stride, IlView{D.pool_il, D.il_len}, signal);
+                       D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool_pm, D.nnz_a, D.pm_stride, IlView{D.pool_il, D.il_len});
     CS3_LAUNCH_CHECK();
     return hipSuccess;
 }
 
 template <int KIND>
-static hipError_t launch_big_block(const DeviceFactor &D, const LaunchGroup &g, int blk, double inv_tol, hipStream_t st, int *signal = nullptr)
+static hipError_t launch_big_block(const DeviceFactor &D, const LaunchGroup &g, int blk, double inv_tol, hipStream_t st)
 {
     const unsigned batch = (unsigned) D.batch;
     const int kb = blk * BIG_NB;
@@ -3323,7 +3318,7 @@ static hipError_t launch_big_block(const DeviceFactor &D, const LaunchGroup &g, 
     const int rem = g.max_r - std::min(start, g.max_r);        // largest trailing order over the group
     const int tiles = 1 + (rem + 63) / 64;
     hipLaunchKernelGGL((k_big_step<KIND>), dim3(tiles, tiles, g.count * batch), dim3(256), 0, st, D.fdesc,
-                       g.first, kb, D.pool_pm, D.pm_stride, D.dbuf, D.dbuf_size, inv_tol, D.status, (int) batch, D.tbuf, signal);
+                       g.first, kb, D.pool_pm, D.pm_stride, D.dbuf, D.dbuf_size, inv_tol, D.status, (int) batch, D.tbuf);
     CS3_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -3331,8 +3326,9 @@ static hipError_t launch_big_block(const DeviceFactor &D, const LaunchGroup &g, 
 // One workgroup per (big front, matrix) when the batch fills the chip by itself and the panels fit the LDS.
 static int wg_panel_ld(const LaunchGroup &g) { return (g.max_r + 1) | 1; }
 // pivots per block step: 16 keeps the kernel within 128 registers, i.e. two workgroups per CU (its phases are serial and
-// latency-bound: 512 matrices took 809 us with one workgroup per CU, in two rounds); CS3_WG_NB=32 is the round-2a form
-static int wg_nb() { static const int nb = (getenv("CS3_WG_NB") && atoi(getenv("CS3_WG_NB")) == 32) ? 32 : 16; return nb; }
+// latency-bound: 512 matrices took 809 us with one workgroup per CU, in two rounds; the 32-pivot form of round 2a is gone)
+constexpr int WG_NB = 16;
+static int wg_nb() { return WG_NB; }
 static size_t wg_lds_bytes(int kind, const LaunchGroup &g)
 {
     return ((size_t) wg_nb() * 33 + (size_t) (kind == CS3_LU ? 2 : 1) * wg_nb() * wg_panel_ld(g)) * sizeof(double);
@@ -3349,14 +3345,9 @@ static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g
     const unsigned batch = (unsigned) D.batch;
     if (g.cls == FC_SUB) return launch_sub_factor(D, g.first, D.fwd_in_factor, inv_tol, st);     // a tier of the bottom forest
     if (big_group_in_one_workgroup(KIND, D.batch, g)) {
-        if (wg_nb() == 16)
-            hipLaunchKernelGGL((k_front_wg<KIND, 16>), dim3((unsigned) g.count, batch), dim3(512), wg_lds_bytes(KIND, g), st, D.fdesc,
-                               g.first, D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool_pm, D.nnz_a, D.pm_stride,
-                               IlView{D.pool_il, D.il_len}, inv_tol, D.status, wg_panel_ld(g), D.tbuf);
-        else
-            hipLaunchKernelGGL((k_front_wg<KIND, 32>), dim3((unsigned) g.count, batch), dim3(512), wg_lds_bytes(KIND, g), st, D.fdesc,
-                               g.first, D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool_pm, D.nnz_a, D.pm_stride,
-                               IlView{D.pool_il, D.il_len}, inv_tol, D.status, wg_panel_ld(g), D.tbuf);
+        hipLaunchKernelGGL((k_front_wg<KIND, WG_NB>), dim3((unsigned) g.count, batch), dim3(512), wg_lds_bytes(KIND, g), st, D.fdesc,
+                           g.first, D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool_pm, D.nnz_a, D.pm_stride,
+                           IlView{D.pool_il, D.il_len}, inv_tol, D.status, wg_panel_ld(g), D.tbuf);
         CS3_LAUNCH_CHECK();
         return hipSuccess;
     }
@@ -3382,27 +3373,24 @@ static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g
     case FC_R32:      // only present when the analysis split the small fronts off (batched handles)
         hipLaunchKernelGGL((k_front_wave<KIND>), grid, dim3(64), lds, st, CS3_FRONT_ARGS); break;
     case FC_R64: {    // (+ the counter and the multipliers of the shared elimination behind the image: [pivots][64])
-        // orders 33..64: the 16 x 16 thread grid (front_lds_body).  CS3_LDS_GRID=0 sends them through the shared elimination
-        // too (four waves x 16 columns): equal on config 3 (their level is set by the assembly), 3.99 against 3.57 ms on 512
-        // batched matrices -- waves that wait for multipliers take issue slots from the other fronts of a full CU
-        static const int lds_grid = !(getenv("CS3_LDS_GRID") && getenv("CS3_LDS_GRID")[0] == '0');
+        // orders 33..64 run on the 16 x 16 thread grid (front_lds_body): through the shared elimination (four waves x 16
+        // columns) they were equal on config 3 and slower on batches (3.99 against 3.57 ms on 512 matrices: waves that
+        // wait for multipliers take issue slots from the other fronts of a full CU)
         const size_t lm = (size_t) 64 * ((std::min(g.max_w, 64) + PAIR_NC - 1) / PAIR_NC * PAIR_NC) + 4;
-        hipLaunchKernelGGL((k_front_mix<KIND>), grid, dim3(256), lds + lm * sizeof(double), st, CS3_FRONT_ARGS, lds_grid); break;
+        hipLaunchKernelGGL((k_front_mix<KIND>), grid, dim3(256), lds + lm * sizeof(double), st, CS3_FRONT_ARGS); break;
     }
     default:
-        // pivots per block step: the one-wave elimination of a block costs NBK^2 column updates, the MFMA update that
-        // follows is cheap, so narrow blocks win (measured: 32 -> 16 took 4 % off the batched config, neutral on config 3)
-        static const int nbk = getenv("CS3_NBK") ? atoi(getenv("CS3_NBK")) : 16;
+        // 16 pivots per block step: the one-wave elimination of a block costs NBK^2 column updates, the MFMA update that
+        // follows is cheap, so narrow blocks win (measured: 32 -> 16 took 4 % off the batched config, neutral on config 3;
+        // 8 equal to 16)
         // the image: r x (r | 1) for LU, the packed lower triangle for Cholesky, one zero entry behind it
         const size_t blds = ((KIND == CS3_LU) ? ld * (size_t) g.max_r : (size_t) g.max_r * (size_t) (g.max_r + 1) / 2) * sizeof(double) + 16;
         // Cholesky has no block-row waves: four waves do all the eliminations of a block step, and a batch prefers more
-        // workgroups per CU to more waves per front (CS3_BLOCK_NW=8 restores eight)
-        static const int nw4 = !(getenv("CS3_BLOCK_NW") && atoi(getenv("CS3_BLOCK_NW")) == 8);
-        if (KIND == CS3_CHOLESKY && nw4 && D.batch >= 16 && nbk > 8 && nbk <= 16)
+        // workgroups per CU to more waves per front
+        if (KIND == CS3_CHOLESKY && D.batch >= 16)
             hipLaunchKernelGGL((k_front_block<CS3_CHOLESKY, 16, 4>), grid, dim3(256), blds, st, CS3_FRONT_ARGS);
-        else if (nbk <= 8) hipLaunchKernelGGL((k_front_block<KIND, 8>), grid, dim3(512), blds, st, CS3_FRONT_ARGS);
-        else if (nbk <= 16) hipLaunchKernelGGL((k_front_block<KIND, 16>), grid, dim3(512), blds, st, CS3_FRONT_ARGS);
-        else hipLaunchKernelGGL((k_front_block<KIND, 32>), grid, dim3(512), blds, st, CS3_FRONT_ARGS);
+        else
+            hipLaunchKernelGGL((k_front_block<KIND, 16>), grid, dim3(512), blds, st, CS3_FRONT_ARGS);
         break;
     }
 #undef CS3_FRONT_ARGS
@@ -3435,12 +3423,9 @@ hipError_t prepare_kernels()
     // the largest LDS-resident class needs more than the default 64 KiB of dynamic LDS
     const int big = 160 * 1024;
     hipError_t e;
-    const void *block_fns[] = {(const void *) k_front_block<CS3_LU, 16>, (const void *) k_front_block<CS3_LU, 32>,
-                               (const void *) k_front_block<CS3_CHOLESKY, 16>, (const void *) k_front_block<CS3_CHOLESKY, 32>,
-                               (const void *) k_front_block<CS3_LU, 8>, (const void *) k_front_block<CS3_CHOLESKY, 8>,
+    const void *block_fns[] = {(const void *) k_front_block<CS3_LU, 16>, (const void *) k_front_block<CS3_CHOLESKY, 16>,
                                (const void *) k_front_block<CS3_CHOLESKY, 16, 4>,
-                               (const void *) k_front_wg<CS3_LU, 16>, (const void *) k_front_wg<CS3_CHOLESKY, 16>,
-                               (const void *) k_front_wg<CS3_LU, 32>, (const void *) k_front_wg<CS3_CHOLESKY, 32>};
+                               (const void *) k_front_wg<CS3_LU, WG_NB>, (const void *) k_front_wg<CS3_CHOLESKY, WG_NB>};
     for (const void *f : block_fns) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, big);
         if (e != hipSuccess) return e;
@@ -3511,14 +3496,12 @@ static hipError_t run_level(const std::vector<LaunchGroup> &groups, size_t g0, s
     if ((e = hipEventRecord(fork, st)) != hipSuccess) return e;
     // the heaviest group (last: big fronts / block kernels sort last) stays on the main stream and is captured FIRST: the
     // runtime keeps a node's first captured dependent in the node's own hardware queue (launch_factor_with_forward)
-    static const bool heavy_first = !(getenv("CS3_SWEEP_FIRST") && getenv("CS3_SWEEP_FIRST")[0] == '1');
-    if (heavy_first && (e = launch(groups[g1 - 1], st)) != hipSuccess) return e;
+    if ((e = launch(groups[g1 - 1], st)) != hipSuccess) return e;
     for (size_t i = 0; i + 1 < ng; ++i) {
         hipStream_t s = fj.side[i % ForkJoin::NSIDE];
         if (i < (size_t) ForkJoin::NSIDE) { if ((e = hipStreamWaitEvent(s, fork, 0)) != hipSuccess) return e; }
         if ((e = launch(groups[g0 + i], s)) != hipSuccess) return e;
     }
-    if (!heavy_first && (e = launch(groups[g1 - 1], st)) != hipSuccess) return e;
     for (size_t i = 0; i < std::min(ng - 1, (size_t) ForkJoin::NSIDE); ++i) {
         hipEvent_t j;
         if ((e = fj.event(&j)) != hipSuccess) return e;
@@ -3642,11 +3625,10 @@ static hipError_t launch_inv_tasks(const DeviceFactor &D, int t0, int t1, hipStr
 // interleaved batch, GEMM sweeps on.
 bool permutation_can_fuse(const DeviceFactor &D, int nrhs)
 {
-    static const bool on = !(getenv("CS3_NO_FUSED_PERMUTE") && getenv("CS3_NO_FUSED_PERMUTE")[0] == '1') &&
-                           !(getenv("CS3_NO_GEMM_SWEEPS") && getenv("CS3_NO_GEMM_SWEEPS")[0] == '1');
+    static const bool on = !(getenv("CS3_NO_GEMM_SWEEPS") && getenv("CS3_NO_GEMM_SWEEPS")[0] == '1');
     // (measured on config 4: the extra row-map round trip per front costs more than the two permutation kernels below a
     // few hundred right-hand sides; at 1024 the fused form saves 0.14 ms of 2.3)
-    static const int min_rhs = getenv("CS3_FUSED_PERMUTE_MIN_RHS") ? atoi(getenv("CS3_FUSED_PERMUTE_MIN_RHS")) : 256;
+    constexpr int min_rhs = 256;
     return on && nrhs >= std::max(min_rhs, RHS_LANES_MIN) && D.il_len == 0;
 }
 
@@ -3727,8 +3709,7 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
     if (g.cls == SK_IL) {
         // the fronts of order <= 16 come first in the group: half the LDS per wave (the front vector of 64 matrices),
         // twice the waves per CU -- these sweeps wait on one round trip per pivot
-        static const bool il16 = !(getenv("CS3_NO_IL16") && getenv("CS3_NO_IL16")[0] == '1');
-        const int n16 = il16 ? g.n16 : 0;
+        const int n16 = g.n16;
         if (n16 > 0) {
             dim3 grid((unsigned) n16, (unsigned) D.ngroups);
             if (forward)
@@ -3748,18 +3729,13 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
                                    IlView{D.pool_il, D.il_len}, X, nrhs, xs, (int) D.batch);
         }
     } else if (g.cls == SK_SMALL && nrhs >= RHS_LANES_MIN) {
-        // the fronts of order <= 16 come first in the group: half the registers per wave, twice the waves per CU
-        // (these sweeps are bound by memory latency times occupancy); the two launches are independent
-        // (off since the slot-round assembly freed the LDS: 256 right-hand sides 1.01 ms split, 0.945 not; 1024: 1.637 / 1.627;
-        //  CS3_SPLIT16=1 turns it on)
-        static const bool split16 = getenv("CS3_SPLIT16") && getenv("CS3_SPLIT16")[0] == '1';
-        const int n16 = (split16 && nrhs >= 256 && g.max_r > 16) ? g.n16 : 0;     // (an extra launch per level: pays with many tiles)
-        if (n16 > 0) launch_rhs_sweep<KIND, 16>(D, g.first, n16, X, nrhs, forward, st);
-        const int f2 = g.first + n16, c2 = g.count - n16;
-        if (g.max_r <= 16) launch_rhs_sweep<KIND, 16>(D, f2, c2, X, nrhs, forward, st);
-        else if (g.max_r <= 24) launch_rhs_sweep<KIND, 24>(D, f2, c2, X, nrhs, forward, st);
-        else if (g.max_r <= 32) launch_rhs_sweep<KIND, 32>(D, f2, c2, X, nrhs, forward, st);
-        else launch_rhs_sweep<KIND, 64>(D, f2, c2, X, nrhs, forward, st);
+        // one instance by the group's largest order (fronts of order <= 32 only: the analysis sends the others to the GEMM
+        // sweeps; a separate launch for the fronts of order <= 16 of a group paid while the assembly went through LDS and
+        // stopped paying with the slot rounds: 256 right-hand sides 1.01 ms split, 0.945 not)
+        if (g.max_r <= 16) launch_rhs_sweep<KIND, 16>(D, g.first, g.count, X, nrhs, forward, st);
+        else if (g.max_r <= 24) launch_rhs_sweep<KIND, 24>(D, g.first, g.count, X, nrhs, forward, st);
+        else if (g.max_r <= 32) launch_rhs_sweep<KIND, 32>(D, g.first, g.count, X, nrhs, forward, st);
+        else return hipErrorInvalidValue;
     } else if (g.cls == SK_SMALL || g.cls == SK_WAVE) {
         if (nrhs == 1) {
             dim3 grid((unsigned) ((g.count + 3) / 4), (unsigned) D.batch, 1);
@@ -3803,11 +3779,10 @@ static hipError_t launch_solve_group(const DeviceFactor &D, const LaunchGroup &g
 // the two groups of a level are adjacent in the schedule and go out as one launch.
 // A handful of small fronts beside the level's workgroup-per-front group (the top of the tree) join that group: a second
 // launch for four fronts costs a dependent launch (sweeps, 11 us) or a fork and a join across hardware queues
-// (factorisation, 13 us), the workgroup kernels take fronts of any order.  CS3_PROMOTE_MAX=0 turns it off.
+// (factorisation, 13 us), the workgroup kernels take fronts of any order.
 static int promote_max()
 {
-    static const int v = [] { const char *e = getenv("CS3_PROMOTE_MAX"); return e ? std::max(0, atoi(e)) : 16; }();
-    return v;
+    return 16;                                   // (8 .. 200 measured identical on config 3: only the top three levels hold such a group)
 }
 
 static void absorb_small_group(std::vector<LaunchGroup> &out, const LaunchGroup &g, int small_cls, int wg_cls)
@@ -3837,7 +3812,7 @@ static std::vector<LaunchGroup> sweep_groups(const std::vector<LaunchGroup> &gro
             merged.push_back(g);
         }
     }
-    if (batch != 1 || promote_max() == 0) return merged;       // (a batch fills the chip with waves: one per front stays cheaper)
+    if (batch != 1) return merged;       // (a batch fills the chip with waves: one per front stays cheaper)
     for (const LaunchGroup &g : merged) absorb_small_group(out, g, SK_WAVE, SK_BLOCK);
     return out;
 }
@@ -3845,7 +3820,7 @@ static std::vector<LaunchGroup> sweep_groups(const std::vector<LaunchGroup> &gro
 // the same for the factorisation of a single matrix: few fronts of order <= 64 beside the level's LDS-image fronts
 static std::vector<LaunchGroup> factor_groups(const DeviceFactor &D, const std::vector<LaunchGroup> &groups)
 {
-    if (D.batch != 1 || promote_max() == 0) return groups;
+    if (D.batch != 1) return groups;
     std::vector<LaunchGroup> out;
     for (const LaunchGroup &g : groups) absorb_small_group(out, g, FC_R64, FC_LDS);
     return out;
@@ -3861,8 +3836,7 @@ hipError_t launch_solve_levels(const DeviceFactor &D, const std::vector<LaunchGr
     // and are independent -- side by side they save 60 us of 1.73 ms at 1024 right-hand sides, 24 us of 0.83 at 128.
     // (re-measured with the fronts of order 33-64 on the GEMM sweeps: the fork now pays from 512 right-hand sides on only
     //  -- 128: 0.82 ms forked, 0.77 in line; 256: equal; 1024: equal to 0.5 %)
-    static const char *sf = getenv("CS3_SOLVE_FORK");
-    const bool solve_parallel = sf ? sf[0] == '1' : nrhs >= 512;
+    const bool solve_parallel = nrhs >= 512;
     auto launch = [&](const LaunchGroup &g, hipStream_t s) {
         return (D.kind == CS3_LU) ? launch_solve_group<CS3_LU>(D, g, X, nrhs, forward, s)
                                   : launch_solve_group<CS3_CHOLESKY>(D, g, X, nrhs, forward, s);
@@ -3885,23 +3859,6 @@ hipError_t launch_solve_levels(const DeviceFactor &D, const std::vector<LaunchGr
         }
     }
     return hipSuccess;
-}
-
-// The overlapped forward sweep does not wait for the factorisation through a cross-queue dependency of the graph: the
-// first dispatch of the side queue then comes 130-200 us after the dependency is met (measured; the main queue keeps
-// dispatching block steps meanwhile), which made the sweep the longer branch once the root's block steps had become
-// faster.  Its branch starts with the graph instead and holds a one-thread kernel that waits for a word in memory, which
-// the first launch AFTER the awaited point sets as it starts (k_big_gather / k_big_step, thread 0): a few microseconds from
-// flag to sweep.  The waiter consumes the flag (1 -> 0; the prologue clears both words anyway) and gives up after about a
-// second -- a sweep that started early gives a wrong answer, not a hung GPU.
-__global__ void k_flag_wait(int *flag, int *timed_out)
-{
-    for (long long it = 0; it < (1ll << 18); ++it) {          // about a second
-        int expected = 1;
-        if (__hip_atomic_compare_exchange_strong(flag, &expected, 0, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-        __builtin_amdgcn_s_sleep(8);
-    }
-    *timed_out = 1;                                  // read_status reports it: the results of this step are not to be used
 }
 
 // Rough cost of a launch group in dependent-launch units, to place the fork below.
@@ -3944,7 +3901,6 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
     static const bool overlap = !(getenv("CS3_NO_OVERLAP") && getenv("CS3_NO_OVERLAP")[0] == '1');
     for (int l = 0; overlap && l + 1 < nlevels; ++l)
         if (tail[l + 1] >= head[l + 1]) fork_level = l;
-    if (const char *fl = getenv("CS3_FORK_LEVEL")) { const int v = atoi(fl); if (overlap && v >= 0 && v + 1 < nlevels) fork_level = v; }
 
     auto sweep = [&](int lo, int hi, hipStream_t s) -> hipError_t {      // forward sweep of levels lo..hi
         for (const LaunchGroup &g : sgroups) {
@@ -3961,29 +3917,20 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
     // b + 1 (k_big_step), so chunk c of the sweep follows on fj.aux as soon as its blocks are home, while the
     // later blocks are still being factorised.
     const LaunchGroup *rootf = nullptr, *roots = nullptr;
-    static const bool pipe_root = !(getenv("CS3_NO_ROOT_PIPE") && getenv("CS3_NO_ROOT_PIPE")[0] == '1');
     // (with many right-hand sides the root sweeps as GEMMs through launch_solve_group like every other group)
-    if (pipe_root && nrhs < RHS_LANES_MIN && nlevels >= 2 && fork_level == nlevels - 2) {
+    if (nrhs < RHS_LANES_MIN && nlevels >= 2 && fork_level == nlevels - 2) {
         int nf = 0, ns = 0;
         for (const LaunchGroup &g : fgroups) if (g.level == nlevels - 1) { ++nf; rootf = &g; }
         for (const LaunchGroup &g : sgroups) if (g.level == nlevels - 1) { ++ns; roots = &g; }
         if (nf != 1 || ns != 1 || rootf->cls != FC_BIG || roots->cls != SK_BIG || rootf->count != roots->count)
             rootf = roots = nullptr;
     }
+    // The side branch is CAPTURED after the next launch of the chain it forks from: the runtime keeps a node's FIRST
+    // captured dependent in the node's own hardware queue and moves the others to another queue, whose first dispatch
+    // then waits 40-60 us (measured: profiles/r02_timeline_fused_step.json) -- the late start must land on the sweep,
+    // which has slack, not on the factorisation.  (Tried and removed, DESIGN.md: the sweep captured first; the block chain
+    // waiting for the side branch before the release; hand-overs through memory words with a waiting kernel.)
     hipEvent_t swept = nullptr, ready_deferred = nullptr;
-    static const bool sweep_first = getenv("CS3_SWEEP_FIRST") && getenv("CS3_SWEEP_FIRST")[0] == '1';   // the round-1 capture order
-    // hand-overs to the side queue through memory words instead of graph dependencies (k_flag_wait), pipelined root only
-    // OFF by default (CS3_FLAG_SYNC=1: 0.645 -> 0.63 ms per step on config 3): the waiting kernel needs the two queues to
-    // run at the same time, and a tool that serialises kernels (rocprofv3 --pmc, a debugger) leaves it alone on the device
-    // until it gives up -- the step then fails with an error instead of running a second slower
-    static const bool flag_env = getenv("CS3_FLAG_SYNC") && getenv("CS3_FLAG_SYNC")[0] == '1';
-    const bool flags = flag_env && rootf && !sweep_first && nlevels >= 3;
-    int *flag_ready = D.status + 1, *flag_home = D.status + 2;
-    // the side branch forks after the first level and is captured after the second: captured first it would take the
-    // graph's primary hardware queue and the factorisation the slow one (capture order, above)
-    hipEvent_t begin = nullptr;
-    int levels_done = 0;
-
     int root_rest = 0;                             // first chunk of the root's sweep that is still to do after the join
     for (size_t f0 = 0; f0 < fgroups.size(); ) {
         const int level = fgroups[f0].level;
@@ -3992,31 +3939,18 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
         if (rootf && level == nlevels - 1) {
             const BigSweepPlan pl = big_sweep_plan(D, *roots, nrhs);
             const int nblk = big_group_blocks(*rootf), cwb = pl.cw / BIG_NB;
-            if ((e = launch_big_gather(D, *rootf, st, flags ? flag_ready : nullptr)) != hipSuccess) return e;
+            if ((e = launch_big_gather(D, *rootf, st)) != hipSuccess) return e;
             // ONE release (every cross-stream edge costs the block chain about 10 us): the first k chunks go to
-            // fj.aux after block launch k * cwb, k the largest count that the remaining launches still cover;
-            // the other chunks follow on st after the join.
-            // CAPTURE ORDER MATTERS: the runtime keeps a node's FIRST captured dependent in the node's own hardware
-            // queue and moves the others to another queue, whose first dispatch then waits 40-60 us (measured:
-            // profiles/r02_timeline_fused_step.json, the root's gather started 46 us after the level below it).  So at
-            // every fork the next launch of the block chain is captured BEFORE the side branch that hangs off the same
-            // node: the chain stays in its queue, the late start lands on the sweep, which has slack.
+            // fj.aux after block launch k * cwb, k the largest count that the remaining launches still cover (one launch
+            // of slack: the side queue starts a chunk 10-15 us after its release); the other chunks follow on st after
+            // the join.
             int k = 0;
-            // (one launch of slack: the side queue starts a chunk 10-15 us after its release)
             while (k < pl.nchunk && (k + 1) * cwb <= nblk && nblk - (k + 1) * cwb >= k + 2) ++k;
-            if (const char *rk = getenv("CS3_ROOT_K")) k = std::max(0, std::min(k, atoi(rk)));
-            // CS3_ABSORB=1: the block chain waits for the side branch before the release launch, so that the released
-            // chunks hang off the chain alone (round 1's form: it paid while the chain hopped queues; with the chain in one
-            // queue the wait only stalls it -- 0.874 -> 0.868 ms per step without, same-box A/B x 3)
-            static const bool absorb = getenv("CS3_ABSORB") && getenv("CS3_ABSORB")[0] == '1';
             hipEvent_t home = nullptr;
             bool side_started = false;
             auto start_side = [&]() -> hipError_t {                        // sweep of the lower levels + the root's gather
                 side_started = true;
-                if (flags) {                                               // (fj.aux already holds the waiting kernel)
-                    hipError_t se;
-                    if ((se = sweep(0, fork_level, fj.aux)) != hipSuccess) return se;
-                } else if (ready_deferred) {
+                if (ready_deferred) {
                     hipError_t se;
                     if ((se = hipStreamWaitEvent(fj.aux, ready_deferred, 0)) != hipSuccess) return se;
                     if ((se = sweep(0, fork_level, fj.aux)) != hipSuccess) return se;
@@ -4025,10 +3959,7 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
             };
             auto release = [&]() -> hipError_t {                           // chunks 0 .. k - 1 hang off block launch k * cwb
                 hipError_t se;
-                if (flags) {
-                    hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(1), 0, fj.aux, flag_home, D.status + 3);
-                    if ((se = hipGetLastError()) != hipSuccess) return se;
-                } else if ((se = hipStreamWaitEvent(fj.aux, home, 0)) != hipSuccess) return se;
+                if ((se = hipStreamWaitEvent(fj.aux, home, 0)) != hipSuccess) return se;
                 for (int c = 0; c < k; ++c) {
                     se = (D.kind == CS3_LU) ? launch_fwd_big_chunk<CS3_LU>(D, *roots, X, nrhs, c, fj.aux)
                                             : launch_fwd_big_chunk<CS3_CHOLESKY>(D, *roots, X, nrhs, c, fj.aux);
@@ -4038,21 +3969,8 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
                 return hipSuccess;
             };
             for (int blk = 0; blk <= nblk; ++blk) {
-                if (absorb && k > 0 && blk == k * cwb) {
-                    // the side branch (sweep of the lower levels, the root's gather) finished long ago: the block chain
-                    // absorbs it here, so that the chunks released below hang off the chain alone -- a chunk with two
-                    // parents in different queues keeps a barrier pending in the side queue for hundreds of
-                    // microseconds, and the chain's dispatches slow down while it does
-                    if (!side_started && (e = start_side()) != hipSuccess) return e;
-                    hipEvent_t pre;
-                    if ((e = fj.event(&pre)) != hipSuccess) return e;
-                    if ((e = hipEventRecord(pre, fj.aux)) != hipSuccess) return e;
-                    if ((e = hipStreamWaitEvent(st, pre, 0)) != hipSuccess) return e;
-                }
-                // (blocks 0 .. k cwb - 1 are home when launch k cwb is complete, i.e. when launch k cwb + 1 starts: it says so)
-                int *sig = (flags && k > 0 && blk == k * cwb + 1) ? flag_home : nullptr;
-                e = (D.kind == CS3_LU) ? launch_big_block<CS3_LU>(D, *rootf, blk, inv_tol, st, sig)
-                                       : launch_big_block<CS3_CHOLESKY>(D, *rootf, blk, inv_tol, st, sig);
+                e = (D.kind == CS3_LU) ? launch_big_block<CS3_LU>(D, *rootf, blk, inv_tol, st)
+                                       : launch_big_block<CS3_CHOLESKY>(D, *rootf, blk, inv_tol, st);
                 if (e != hipSuccess) return e;
                 if (!side_started && (e = start_side()) != hipSuccess) return e;      // after the chain's first block is captured
                 if (home && (e = release()) != hipSuccess) return e;                  // after the block that follows the release point
@@ -4073,14 +3991,6 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
                                       : launch_front_group<CS3_CHOLESKY>(D, g, inv_tol, s);
         });
         if (e != hipSuccess) return e;
-        if (flags && ++levels_done == 1) {             // (as a root node of the graph, captured here: no better, 0.632 vs 0.628 ms)
-            if ((e = fj.event(&begin)) != hipSuccess) return e;
-            if ((e = hipEventRecord(begin, st)) != hipSuccess) return e;
-        } else if (flags && levels_done == 2) {
-            if ((e = hipStreamWaitEvent(fj.aux, begin, 0)) != hipSuccess) return e;
-            hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(1), 0, fj.aux, flag_ready, D.status + 3);
-            CS3_LAUNCH_CHECK();
-        }
         if (ready_deferred && !rootf) {            // the level above the fork has been captured: now the side branch
             if ((e = hipStreamWaitEvent(fj.aux, ready_deferred, 0)) != hipSuccess) return e;
             if ((e = sweep(0, fork_level, fj.aux)) != hipSuccess) return e;
@@ -4092,13 +4002,7 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
             hipEvent_t ready;                      // panels of levels 0..fork_level are final
             if ((e = fj.event(&ready)) != hipSuccess) return e;
             if ((e = hipEventRecord(ready, st)) != hipSuccess) return e;
-            if (!sweep_first) { ready_deferred = ready; }      // captured after the chain above has begun (see the root's chain)
-            else {
-                if ((e = hipStreamWaitEvent(fj.aux, ready, 0)) != hipSuccess) return e;
-                if ((e = sweep(0, fork_level, fj.aux)) != hipSuccess) return e;
-                if ((e = fj.event(&swept)) != hipSuccess) return e;
-                if ((e = hipEventRecord(swept, fj.aux)) != hipSuccess) return e;
-            }
+            ready_deferred = ready;                // captured after the chain above has begun (see the root's chain)
         }
         f0 = f1;
     }

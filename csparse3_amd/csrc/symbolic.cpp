@@ -111,20 +111,7 @@ double seconds_since(std::chrono::steady_clock::time_point t0)
 
 i64 il_rmax()
 {
-    static const i64 v = [] { const char *e = std::getenv("CS3_IL_RMAX"); i64 x = e ? std::atoll(e) : IL_RMAX_DEFAULT; return std::min<i64>(std::max<i64>(x, 0), IL_RMAX); }();
-    return v;
-}
-
-// Interleaved batches: fronts of order il_rmax() < r <= il_sweep_rmax() keep their lane = row factor kernel but store
-// their PANELS in the interleaved region, so that the sweeps of these fronts run lane = matrix as well (panels streamed
-// at memory rate, no index lists) -- the lane = row sweeps spend 60 % of their wave cycles parked on round trips.
-// OFF by default (CS3_IL_SWEEP_RMAX=32 turns it on): measured 3.91 against 3.87 ms on 512 matrices -- the backward sweeps
-// gain 90 us, but a level with few such fronts has only batch / 64 waves per front and the forward assembly (strided
-// contribution vectors) is no faster lane = matrix.
-i64 il_sweep_rmax()
-{
-    static const i64 v = [] { const char *e = std::getenv("CS3_IL_SWEEP_RMAX"); i64 x = e ? std::atoll(e) : 0; return std::min<i64>(std::max<i64>(x, 0), IL_RMAX); }();
-    return v;
+    return IL_RMAX_DEFAULT;
 }
 
 int front_class(i64 r, i64 w, bool split_small, bool interleave)
@@ -134,8 +121,7 @@ int front_class(i64 r, i64 w, bool split_small, bool interleave)
     if (r <= 64) return FC_R64;       // one launch: k_front_mix (one wave for r <= 32, 16 x 16 threads above)
     // k_front_block: the image fits the LDS ((136*137 + 4*136 + 6) doubles = 153 KB of 160 KB) and the rows below
     // the first pivot block fit four stacked groups of 32
-    static const bool wg_all = std::getenv("CS3_WG_ALL") && std::getenv("CS3_WG_ALL")[0] == '1';
-    if (r <= 136 && r - std::min<i64>(w, 16) <= 128 && !(wg_all && split_small)) return FC_LDS;
+    if (r <= 136 && r - std::min<i64>(w, 16) <= 128) return FC_LDS;
     return FC_BIG;
 }
 
@@ -161,13 +147,10 @@ struct ForestLimits {
 static ForestLimits forest_limits()
 {
     ForestLimits L;
-    if (const char *e = std::getenv("CS3_SUB_FRONTS")) L.fronts = std::max<i64>(1, std::atoll(e));
-    if (const char *e = std::getenv("CS3_SUB_ARENA")) L.arena = std::max<i64>(64, std::atoll(e));
-    if (const char *e = std::getenv("CS3_SUB_BINS")) L.bins = std::max<i64>(1, std::atoll(e));
-    if (const char *e = std::getenv("CS3_SUB_TIERS")) L.max_tiers = std::max<i64>(0, std::atoll(e));
+    // (the other limits were swept on config 3 and are constants now: 32 / 24 fronts per task 0.639 / 0.655 against 0.611;
+    //  512 bins equal; sharing from 4 / 8 / 12 pivots on equal; shared levels of up to 8 fronts 0.634, up to 2 0.608;
+    //  2 tiers of height 3 / 4: 0.609 / 0.633, 3 tiers of height 2: 0.636)
     if (const char *e = std::getenv("CS3_SUB_HEIGHT")) L.max_height = std::max<i64>(1, std::atoll(e));
-    if (const char *e = std::getenv("CS3_SUB_COOP_W")) L.coop_w = std::max<i64>(1, std::atoll(e));
-    if (const char *e = std::getenv("CS3_SUB_COOP_LEVEL")) L.coop_level = std::max<i64>(0, std::atoll(e));
     return L;
 }
 
@@ -525,16 +508,12 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     //          (From 256 matrices on: 64 matrices -- one lane = matrix group, the per-GPU share of config 5 on eight GPUs --
     //          are still latency-bound and prefer the shallow tree: 1.31 ms with this economy, 1.21 without; 96: 1.48 / 1.36;
     //          128 and 192: equal; 512: 3.60 / 3.85.)
-    static const i64 economy_min = std::getenv("CS3_BATCH_ECONOMY_MIN") ? std::atoll(std::getenv("CS3_BATCH_ECONOMY_MIN")) : 256;
-    const bool batch_economy = S.batch >= economy_min;
+    const bool batch_economy = S.batch >= 256;
     // (single matrices: 0.7 since round 2 -- re-measured with this round's kernels: 50k 0.871 -> 0.829 ms, 10k 0.57 -> 0.48,
     //  20k 0.75 -> 0.71, 100k equal, 200k 2.76 -> 2.62; the 0.5 of round 1 had been set with slower block-front kernels)
     double relax_z = batch_economy ? 0.25 : 0.7; i64 relax_w = batch_economy ? 4 : 8;
     if (const char *e = std::getenv("CS3_RELAX_Z")) relax_z = std::atof(e);
-    if (const char *e = std::getenv("CS3_RELAX_W")) relax_w = std::atoll(e);
     i64 relax_r = 32; double relax_z2 = 0.25;          // fronts beyond the one-wave kernels (r > 32) merge only when nearly free
-    if (const char *e = std::getenv("CS3_RELAX_R")) relax_r = std::atoll(e);
-    if (const char *e = std::getenv("CS3_RELAX_Z2")) relax_z2 = std::atof(e);
     std::vector<i64> mw(nf), mr(nf), mc0(nf);
     std::vector<double> mz(nf, 0.0);
     std::vector<char> alive(nf, 1);
@@ -544,8 +523,8 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     const i64 lds_r = 136, big_nb = 32;
     std::vector<i32> into(nf, -1);           // merged-into link; the alive supernode is the top of its chain
     auto alive_of = [&](i32 f) { while (into[f] >= 0) f = into[f]; return f; };
-    i64 relax_passes = 4;                    // later passes see parents at their merged size (a thin first member of a
-    if (const char *e = std::getenv("CS3_RELAX_PASSES")) relax_passes = std::atoll(e);   // wide root hides how cheap a merge is)
+    const i64 relax_passes = 4;              // later passes see parents at their merged size (a thin first member of a
+                                             // wide root hides how cheap a merge is)
     for (i64 pass = 0; pass < relax_passes; ++pass) {
         bool changed = false;
         for (i32 s = 0; s < nf; ++s) {
@@ -617,9 +596,10 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     //          small batches: a large batch fills the chip level by level and runs its small fronts lane = matrix)
     {
         static const bool sub_on = !(std::getenv("CS3_SUBTREE") && std::getenv("CS3_SUBTREE")[0] == '0');
-        static const i64 sub_max_batch = std::getenv("CS3_SUB_MAX_BATCH") ? std::atoll(std::getenv("CS3_SUB_MAX_BATCH")) : 1;
+        // (single matrices: batches of 16 .. 64 Cholesky matrices of 5000 columns measured 1.02 .. 2.1 ms through the forest
+        //  against 0.77 .. 1.12 level by level)
         S.sn_tier.assign(ns, -1);
-        if (sub_on && S.batch <= sub_max_batch) build_forest(S, forest_limits());
+        if (sub_on && S.batch == 1) build_forest(S, forest_limits());
     }
     const i32 ntiers = (i32) S.sub_tiers.size();
     auto in_forest = [&](i32 s) { return S.sn_tier[s] >= 0; };
@@ -649,12 +629,12 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     // Single matrices, top of the tree: a level that holds fronts beyond the LDS runs their chain of block launches anyway;
     // a handful of smaller fronts on the same level then ride that chain (dense r x r buffers, the same launches) instead of
     // a launch of their own beside it -- the fork and the join across hardware queues cost the level 12-17 us, the chain
-    // takes no longer for two more tiles (round 2, profiles/r02_timeline_fused_step.json).  CS3_RIDE_MAX=0: off.
+    // takes no longer for two more tiles (round 2, profiles/r02_timeline_fused_step.json).
     std::vector<i32> lvl(ns, 0);             // height above the forest (the whole tree when there is none)
     for (i32 s = 0; s < ns; ++s) { const i32 p = S.sn_parent[s]; if (p >= 0 && !in_forest(s)) lvl[p] = std::max(lvl[p], lvl[s] + 1); }
     std::vector<char> ride(ns, 0);
     {
-        static const i64 ride_max = std::getenv("CS3_RIDE_MAX") ? std::atoll(std::getenv("CS3_RIDE_MAX")) : 8;
+        const i64 ride_max = 8;
         i32 nl = 0;
         for (i32 s = 0; s < ns; ++s) nl = std::max(nl, lvl[s] + 1);
         std::vector<i64> big_w(nl, 0), small_n(nl, 0), small_w(nl, 0);
@@ -674,15 +654,8 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         if (in_forest(s)) return (int) FC_SUB;
         return ride[s] ? (int) FC_BIG : front_class(order_r(s), width(s), S.batch >= 8, interleave);
     };
-    S.sn_il_panels.assign(ns, 0);
-    for (i32 s = 0; s < ns && interleave; ++s) {     // ... then the panels of the lane = row fronts that sweep lane = matrix
-        const i64 w = width(s), r = order_r(s);
-        if (in_forest(s) || front_class(r, w, S.batch >= 8, interleave) != FC_R32 || r > il_sweep_rmax()) continue;
-        S.sn_il_panels[s] = 1;
-        S.lpan_off[s] = voff;                        // dense addressing (i, j) -> i + j r like the FC_IL fronts: L in the
-        if (kind == CS3_LU) { S.upan_off[s] = voff + w * r; S.u_sk[s] = 1; S.u_sj[s] = (i32) r; }     // first w columns, U12
-        voff += (kind == CS3_LU) ? r * r : r * w;    // in rows < w of the others (the block below it stays unused)
-    }
+    // (interleaved PANELS for the lane = row fronts of order 17..32, so that their sweeps run lane = matrix too, were built and
+    //  measured in round 2: 3.91 against 3.87 ms on 512 matrices -- removed)
     S.il_len = voff;
     for (i32 s = 0; s < ns; ++s) {                   // panels of the LDS-resident fronts
         const i64 w = width(s), r = order_r(s), nb = r - w;
@@ -695,7 +668,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
             double m = (double) (r - k - 1);
             S.flops += (kind == CS3_LU) ? (m + 2.0 * m * m) : (m + m * (m + 1.0) + 1.0);
         }
-        if (S.sn_class[s] == FC_BIG || S.sn_class[s] == FC_IL || S.sn_il_panels[s]) continue;
+        if (S.sn_class[s] == FC_BIG || S.sn_class[s] == FC_IL) continue;
         S.lpan_off[s] = voff; voff += r * w;
         // U panel w x nb, pivot rows contiguous: a wave whose lanes are rows stores and reads it coalesced
         if (kind == CS3_LU) { S.upan_off[s] = voff; voff += nb * w; S.u_sk[s] = 1; S.u_sj[s] = (i32) w; }
@@ -887,11 +860,6 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         if (g.cls == FC_SUB) { g.first = g.level; g.count = S.sub_tiers[g.level].ntasks; }   // a tier: `first` names it, one workgroup per task
         S.groups.push_back(g);
     }
-    if (std::getenv("CS3_DEBUG_GROUPS"))
-        for (const LaunchGroup &g : S.groups)
-            std::fprintf(stderr, "factor group level %d class %d count %d max_r %d max_w %d\n", g.level, g.cls,
-                         g.count, g.max_r, g.max_w);
-
     // ---- 10b. forward-solve gather lists and the solve schedule
     S.fasm_ptr.assign(ns + 1, 0);
     S.fasm_src.clear(); S.fasm_tgt.clear(); S.flong_src.clear();
@@ -915,9 +883,9 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     // lane = right-hand-side sweeps serve fronts up to this order; beyond it the GEMM sweeps (inverted diagonal blocks,
     // f64 MFMA) take over.  32 since round 2: the 64-row instance of the lane = right-hand-side kernels holds 128 register
     // pairs per lane (one wave per SIMD) and measured 45 us per level on a handful of fronts, the GEMM pair 19.
-    static const i64 small_rmax = std::getenv("CS3_RHS_LANES_RMAX") ? std::atoll(std::getenv("CS3_RHS_LANES_RMAX")) : 32;
+    const i64 small_rmax = 32;
     auto solve_kind = [&](i32 s) {
-        if (S.sn_class[s] == FC_IL || S.sn_il_panels[s]) return (int) SK_IL;
+        if (S.sn_class[s] == FC_IL) return (int) SK_IL;
         if (order_r(s) <= small_rmax) return (int) SK_SMALL;
         if (order_r(s) <= 128 && width(s) <= 64) return (int) SK_WAVE;
         // wide big fronts: one launch per chunk with many workgroups for a lone matrix; a batch fills the chip with one

@@ -611,8 +611,8 @@ int cs3_get_info(cs3_handle h, cs3_info *info)
     if (!info) { set_error("cs3_get_info: null output"); return CS3_ERR_ARG; }
     const Symbolic &S = h->S;
     info->n = S.n; info->nnz_a = S.nnzA;
-    info->nnz_l = S.Lp.empty() ? 0 : S.Lp[S.n];
-    info->nnz_u = (S.kind == CS3_LU && !S.Up.empty()) ? S.Up[S.n] : 0;
+    info->nnz_l = S.nnz_l;
+    info->nnz_u = S.nnz_u;
     info->nsuper = S.nsuper; info->nlevels = S.nlevels;
     info->max_front = S.max_front; info->max_width = S.max_width;
     info->factor_bytes = S.vals_size * (int64_t) sizeof(double);
@@ -827,6 +827,8 @@ int cs3_get_factors(cs3_handle h, int64_t b, int32_t *Lp, int32_t *Li, double *L
     const Symbolic &S = h->S;
     if (b < 0 || b >= h->batch) { set_error("cs3_get_factors: batch index out of range"); return CS3_ERR_ARG; }
     if (S.kind == CS3_CHOLESKY && (Up || Ui || Ux)) { set_error("cs3_get_factors: Cholesky has no U"); return CS3_ERR_ARG; }
+    try { build_csc_factors(h->S); }                           // (first request: the CSC view of the factors is built now)
+    catch (const std::exception &e) { set_error(e.what()); return CS3_ERR_ALLOC; }
     const i64 lnz = S.Lp[S.n];
     if (Lp) std::memcpy(Lp, S.Lp.data(), (size_t) (S.n + 1) * sizeof(int32_t));
     if (Li) std::memcpy(Li, S.Li.data(), (size_t) lnz * sizeof(int32_t));

@@ -177,7 +177,11 @@ struct Symbolic {
     i32 nlevels = 0;
     std::vector<i32> sched;                   // supernode ids grouped by (level, class)
     std::vector<LaunchGroup> groups;          // ascending level
-    // factors in CSC form
+    // exact structures of the fundamental supernodes (before amalgamation): what the exported CSC factors hold
+    std::vector<i32> fsn_ptr, fst_idx;
+    std::vector<i64> fst_ptr;
+    i64 nnz_l = 0, nnz_u = 0;
+    // factors in CSC form, built on first use (build_csc_factors)
     std::vector<i32> Lp, Li, Up, Ui;
     std::vector<i64> Lmap, Umap;              // pool offsets; -1 = constant 1.0 (unit diagonal)
     i64 max_front = 0, max_width = 0;
@@ -195,6 +199,8 @@ constexpr i32 ASM_LONG = 0x40000000;          // flag on a target: sources are l
 // Full analysis.  order: cs3_order.  Throws std::runtime_error on bad input.
 void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
              const i32 *q_given, Symbolic &S, i64 batch = 1);
+
+void build_csc_factors(Symbolic &S);
 
 // Level schedule of a general triangular CSC matrix (cs3_csc_lsolve/usolve).
 struct TriSchedule {

@@ -255,9 +255,9 @@ static void build_forest(Symbolic &S, const ForestLimits &lim)
 }
 
 // Second half, once the pool is laid out and the entries of A are sorted to their fronts: descriptors, child and row
-// lists, scatter lists of A.  from_a[s] = (target in the LDS image, ~entry of Ax) of forest front s.
+// lists, scatter lists of A.  fa_item[fa_ptr[s] ..) = (target in the LDS image, ~entry of Ax) of forest front s.
 template <class Item>
-static void fill_forest(Symbolic &S, std::vector<std::vector<Item>> &from_a)
+static void fill_forest(Symbolic &S, const std::vector<i64> &fa_ptr, const std::vector<Item> &fa_item)
 {
     const size_t nfr = S.sub_sn.size();
     S.sub_fronts.assign(nfr, SubFront{});
@@ -307,13 +307,13 @@ static void fill_forest(Symbolic &S, std::vector<std::vector<Item>> &from_a)
                 d.child_count = (i32) S.sub_child.size() / 4 - d.child_begin;
                 d.a_begin = (i32) S.sub_a_tgt.size();
                 // (target: row | column << 8 of the front; from_a holds row + column (r | 1))
-                for (const Item &it : from_a[s]) {
+                for (i64 e = fa_ptr[s]; e < fa_ptr[s + 1]; ++e) {
+                    const Item &it = fa_item[e];
                     const i32 ld = (i32) (r | 1);
                     S.sub_a_tgt.push_back((it.tgt % ld) | ((it.tgt / ld) << 8));
                     S.sub_a_src.push_back(~it.src);
                 }
                 d.a_count = (i32) S.sub_a_tgt.size() - d.a_begin;
-                std::vector<Item>().swap(from_a[s]);
             }
             K.nrel = (i32) S.sub_rel.size() - K.rel0; K.nchild = (i32) S.sub_child.size() / 4 - K.child0;
             T.max_rel = std::max(T.max_rel, K.nrel); T.max_child = std::max(T.max_child, K.nchild);
@@ -370,6 +370,15 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     }
     S.t_order = seconds_since(t0);
     t0 = std::chrono::steady_clock::now();
+    // (CS3_DUMP_GROUPS=1 also prints where the analysis spends its time)
+    static const bool dump_times = std::getenv("CS3_DUMP_GROUPS") != nullptr;
+    auto t_step = t0;
+    auto tick = [&](const char *what) {
+        if (!dump_times) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "analysis %-44s %7.2f ms\n", what, 1e3 * std::chrono::duration<double>(now - t_step).count());
+        t_step = now;
+    };
 
     // ---- 2. strict upper triangle of P (A + A') P' in the fill-reducing order
     std::vector<i32> pinv0(n);
@@ -385,6 +394,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         Bp[k + 1] = (i32) Bi.size();
     }
 
+    tick("2. permuted upper triangle");
     // ---- 3. etree, postorder, column counts (labels: position in q_amd)
     S.parent_amd.resize(n); S.post_amd.resize(n); S.count_amd.resize(n);
     etree_upper(n, Bp.data(), Bi.data(), S.parent_amd.data());
@@ -392,6 +402,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     cholesky_counts(n, Bp.data(), Bi.data(), S.parent_amd.data(), S.post_amd.data(),
                     S.count_amd.data());
 
+    tick("3. etree, postorder, counts");
     // ---- 4. pivot order = fill-reducing order composed with a postorder of the
     //         etree.  Any postorder gives the same factors up to a symmetric
     //         permutation; this one visits the TALLEST child of every node last, so
@@ -444,9 +455,12 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         S.colcount[k] = S.count_amd[old];
     }
 
+    tick("4. pivot order");
     // ---- 5a. fundamental supernodes: maximal runs j-1 -> j with parent[j-1] = j
     //          and colcount[j] = colcount[j-1] - 1 (identical structure below the run)
-    std::vector<i32> fsn_ptr, fcol2sn(n);
+    std::vector<i32> &fsn_ptr = S.fsn_ptr;       // (kept: build_csc_factors reads the exact structures later)
+    std::vector<i32> fcol2sn(n);
+    fsn_ptr.clear();
     for (i64 j = 0; j < n; ++j) {
         bool join = j > 0 && S.parent[j - 1] == j && S.colcount[j] == S.colcount[j - 1] - 1;
         if (!join) fsn_ptr.push_back((i32) j);
@@ -460,9 +474,11 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         if (S.parent[last] >= 0) fparent[s] = fcol2sn[S.parent[last]];
     }
     // exact row structure of every fundamental supernode (size = column count)
-    std::vector<i64> fst_ptr(nf + 1, 0);
+    std::vector<i64> &fst_ptr = S.fst_ptr;
+    fst_ptr.assign(nf + 1, 0);
     for (i32 s = 0; s < nf; ++s) fst_ptr[s + 1] = fst_ptr[s] + S.colcount[fsn_ptr[s]];
-    std::vector<i32> fst_idx(fst_ptr[nf]);
+    std::vector<i32> &fst_idx = S.fst_idx;
+    fst_idx.assign(fst_ptr[nf], 0);
     {
         std::vector<i32> fchild_ptr(nf + 1, 0), fchild_idx;
         for (i32 s = 0; s < nf; ++s) if (fparent[s] >= 0) ++fchild_ptr[fparent[s] + 1];
@@ -498,6 +514,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         }
     }
 
+    tick("5a. fundamental supernodes + structures");
     // ---- 5b. relaxed amalgamation: a supernode absorbs its LAST child (the one
     //          whose columns end where its own begin) when that adds few explicit
     //          zeros.  Every dependent launch costs microseconds on the device,
@@ -573,6 +590,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
             if (S.sn_parent[s] >= 0) S.child_idx[fill[S.sn_parent[s]]++] = s;
     }
 
+    tick("5b. amalgamation");
     // ---- 6. row structure of every (merged) front: its own columns, then the
     //         structure below the supernode that closes it (a superset of every
     //         absorbed member's, so the extra rows hold explicit zeros)
@@ -592,6 +610,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         for (i64 p = fst_ptr[t] + wt; p < fst_ptr[t + 1]; ++p) st[cnt++] = fst_idx[p];
     }
 
+    tick("6. front structures");
     // ---- 6b. the bottom forest: subtrees of small fronts that one workgroup walks in one launch (single matrices and
     //          small batches: a large batch fills the chip level by level and runs its small fronts lane = matrix)
     {
@@ -606,6 +625,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     // (a forest front whose parent sits in the same tier sits in the same task: its contribution block never leaves the LDS)
     auto block_stays_in_lds = [&](i32 s) { const i32 p = S.sn_parent[s]; return in_forest(s) && p >= 0 && S.sn_tier[p] == S.sn_tier[s]; };
 
+    tick("6b. forest");
     // ---- 7. size classes, pool layout, child -> parent relative indices
     S.sn_class.assign(ns, 0);
     S.lpan_off.assign(ns, 0); S.upan_off.assign(ns, 0); S.cb_off.assign(ns, 0); S.cv_off.assign(ns, 0);
@@ -713,6 +733,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         }
     }
 
+    tick("7. classes, layout, relative indices");
     // ---- 8. levels (leaves = 0)
     S.sn_level.assign(ns, 0);
     for (i32 s = 0; s < ns; ++s) {          // children precede parents in postorder
@@ -725,6 +746,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     S.sn_tlevel.assign(ns, 0);
     for (i32 s = 0; s < ns; ++s) S.sn_tlevel[s] = in_forest(s) ? S.sn_tier[s] : ntiers + lvl[s];
 
+    tick("8. levels");
     // ---- 9. assembly lists: every entry of a front is the sum of its sources
     auto find_row = [&](i32 s, i32 row) -> i64 {
         const i32 *st = S.st_idx.data() + S.st_ptr[s];
@@ -768,26 +790,48 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         }
         pad_to_boundary();
     };
-    std::vector<std::vector<Item>> from_a(ns);
+    // The entries of A by front (fa_ptr / fa_item: target in the front, ~entry of Ax), in the order of A.  Bucketed by
+    // supernode first (a stable counting sort), so that a front's rows are located through ONE position map filled per
+    // front instead of a binary search per entry (half of this step's time at 500 000 entries).
     bool has_upper = false;
     if (kind == CS3_CHOLESKY)
         for (i64 j = 0; j < n && !has_upper; ++j)
             for (i64 p = Ap[j]; p < Ap[j + 1]; ++p) if (Ai[p] < j) { has_upper = true; break; }
-    for (i64 jo = 0; jo < n; ++jo) {
-        for (i64 p = Ap[jo]; p < Ap[jo + 1]; ++p) {
-            i64 io = Ai[p];
-            i32 i2 = S.pinv[io], j2 = S.pinv[jo];
-            if (kind == CS3_CHOLESKY) {
+    std::vector<i64> fa_ptr(ns + 1, 0);
+    std::vector<Item> fa_item;
+    {
+        std::vector<i32> ent_sn(nnzA), ent_col(nnzA);
+        for (i64 jo = 0; jo < n; ++jo) {
+            const i32 j2 = S.pinv[jo];
+            for (i64 p = Ap[jo]; p < Ap[jo + 1]; ++p) {
+                const i64 io = Ai[p];
+                const i32 i2 = S.pinv[io];
                 // cs_chol reads the upper triangle of A; a lower-only input is mirrored
-                bool use = (io == jo) || (has_upper ? io < jo : io > jo);
-                if (!use) continue;
-                if (i2 < j2) std::swap(i2, j2);
+                const bool use = (kind != CS3_CHOLESKY) || (io == jo) || (has_upper ? io < jo : io > jo);
+                const i32 sn = use ? S.col2sn[std::min(i2, j2)] : -1;
+                ent_sn[p] = sn; ent_col[p] = (i32) jo;
+                if (sn >= 0) ++fa_ptr[sn + 1];
             }
-            const i32 s = S.col2sn[std::min(i2, j2)];
-            const i64 c0 = S.sn_ptr[s], c1 = S.sn_ptr[s + 1];
-            const i64 ti = (i2 < c1) ? i2 - c0 : find_row(s, i2);
-            const i64 tj = (j2 < c1) ? j2 - c0 : find_row(s, j2);
-            from_a[s].push_back(Item{target_of(s, ti, tj), (i32) ~p});
+        }
+        for (i32 sn = 0; sn < ns; ++sn) fa_ptr[sn + 1] += fa_ptr[sn];
+        std::vector<i64> fill(fa_ptr.begin(), fa_ptr.end() - 1);
+        std::vector<i32> order(fa_ptr[ns]);
+        for (i64 p = 0; p < nnzA; ++p) if (ent_sn[p] >= 0) order[fill[ent_sn[p]]++] = (i32) p;
+        fa_item.resize(order.size());
+        std::vector<i32> where(n, -1);                       // position of a (permuted) row in the current front's structure
+        for (i32 sn = 0; sn < ns; ++sn) {
+            const i32 *st = S.st_idx.data() + S.st_ptr[sn];
+            const i64 r = order_r(sn);
+            for (i64 k = 0; k < r; ++k) where[st[k]] = (i32) k;
+            for (i64 e = fa_ptr[sn]; e < fa_ptr[sn + 1]; ++e) {
+                const i64 p = order[e];
+                i32 i2 = S.pinv[Ai[p]], j2 = S.pinv[ent_col[p]];
+                if (kind == CS3_CHOLESKY && i2 < j2) std::swap(i2, j2);
+                const i32 ti = where[i2], tj = where[j2];
+                if (ti < 0 || tj < 0) throw std::runtime_error("analyze: entry outside the symbolic structure");
+                fa_item[e] = Item{target_of(sn, ti, tj), (i32) ~p};
+            }
+            for (i64 k = 0; k < r; ++k) where[st[k]] = -1;
         }
     }
     S.asm_ptr.assign(ns + 1, 0);
@@ -795,15 +839,15 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     S.ila_ptr.assign(ns + 1, 0);
     S.ila_pairs.clear();
     {
-        std::vector<Item> items;
+        std::vector<Item> items, sorted;
+        std::vector<i64> sort_count;
         for (i32 s = 0; s < ns; ++s) {
             if (in_forest(s)) {                 // assembled by extend-add inside its task (fill_forest below): no gather list
                 S.asm_ptr[s + 1] = (i64) S.asm_tgt.size();
                 S.ila_ptr[s + 1] = (i64) (S.ila_pairs.size() / 2);
                 continue;
             }
-            items.assign(from_a[s].begin(), from_a[s].end());
-            std::vector<Item>().swap(from_a[s]);
+            items.assign(fa_item.begin() + fa_ptr[s], fa_item.begin() + fa_ptr[s + 1]);
             for (i32 cp = S.child_ptr[s]; cp < S.child_ptr[s + 1]; ++cp) {
                 const i32 c = S.child_idx[cp];
                 const i64 nbc = order_r(c) - width(c);
@@ -813,7 +857,18 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
                     for (i64 ii = (kind == CS3_CHOLESKY ? jj : 0); ii < nbc; ++ii)
                         items.push_back(Item{target_of(s, rel[ii], rel[jj]), (i32) (base + ii + jj * ldc)});
             }
-            std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.tgt < b.tgt; });
+            {
+                // stable counting sort by target (targets are positions inside the front's image or buffer: a range of at
+                // most r (r | 1), against half a million items at the top of a 50 000-column tree)
+                const i64 r = order_r(s);
+                const i64 base = (S.sn_class[s] == FC_BIG) ? S.lpan_off[s] : 0, range = r * (r | 1) + 1;
+                sort_count.assign((size_t) range + 1, 0);
+                for (const Item &it : items) ++sort_count[(size_t) (it.tgt - base) + 1];
+                for (i64 t = 0; t < range; ++t) sort_count[(size_t) t + 1] += sort_count[(size_t) t];
+                sorted.resize(items.size());
+                for (const Item &it : items) sorted[(size_t) sort_count[(size_t) (it.tgt - base)]++] = it;
+                items.swap(sorted);
+            }
             if (S.sn_class[s] == FC_IL) {
                 // lane = matrix assembly: (target, source) pairs in target order in which EVERY stored entry of the
                 // front appears (an entry without a source starts at zero), so each is written exactly once
@@ -836,8 +891,9 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         }
     }
     if (S.asm_tgt.size() >= ((size_t) 1 << 31)) throw std::runtime_error("analyze: assembly list exceeds 32-bit offsets");
-    if (ntiers > 0) fill_forest(S, from_a);
+    if (ntiers > 0) fill_forest(S, fa_ptr, fa_item);
 
+    tick("9. assembly lists");
     // ---- 10. launch groups by (level, size class)
     S.sched.resize(ns);
     std::iota(S.sched.begin(), S.sched.end(), 0);
@@ -860,6 +916,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
         if (g.cls == FC_SUB) { g.first = g.level; g.count = S.sub_tiers[g.level].ntasks; }   // a tier: `first` names it, one workgroup per task
         S.groups.push_back(g);
     }
+    tick("10. launch groups");
     // ---- 10b. forward-solve gather lists and the solve schedule
     S.fasm_ptr.assign(ns + 1, 0);
     S.fasm_src.clear(); S.fasm_tgt.clear(); S.flong_src.clear();
@@ -1011,7 +1068,36 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
                     T.max_levels, T.max_rel, T.max_child, T.max_arena, T.max_r);
     }
 
-    // ---- 11. factors in CSC form: L diagonal first, U diagonal last.  Only the
+    tick("10b. sweep lists and schedules");
+    // ---- 11. the factors in CSC form are built when somebody asks for them (build_csc_factors): only their sizes here
+    S.nnz_l = 0;
+    for (i64 j = 0; j < n; ++j) S.nnz_l += S.colcount[j];
+    S.nnz_u = (kind == CS3_LU) ? S.nnz_l : 0;     // (the pattern is symmetric: row k of U mirrors column k of L)
+    S.Lp.clear(); S.Li.clear(); S.Up.clear(); S.Ui.clear(); S.Lmap.clear(); S.Umap.clear();
+    S.t_symbolic = seconds_since(t0);
+}
+
+
+// Factors in CSC form (cs3_get_factors): column pointers, row indices and where each entry lives in the pool.  Built on
+// first use -- a caller that only solves never pays for it (15 ms of a 70 ms analysis at 50 000 columns).
+void build_csc_factors(Symbolic &S)
+{
+    if (!S.Lp.empty() || S.n == 0) { if (S.n == 0 && S.Lp.empty()) { S.Lp.assign(1, 0); if (S.kind == CS3_LU) S.Up.assign(1, 0); } return; }
+    const i64 n = S.n;
+    const int kind = S.kind;
+    const std::vector<i32> &fsn_ptr = S.fsn_ptr, &fst_idx = S.fst_idx;
+    const std::vector<i64> &fst_ptr = S.fst_ptr;
+    const i32 nf = (i32) fsn_ptr.size() - 1;
+    auto width = [&](i32 s) -> i64 { return S.sn_ptr[s + 1] - S.sn_ptr[s]; };
+    auto order_r = [&](i32 s) -> i64 { return S.st_ptr[s + 1] - S.st_ptr[s]; };
+    auto find_row = [&](i32 s, i32 row) -> i64 {
+        const i32 *st = S.st_idx.data() + S.st_ptr[s];
+        const i64 r = order_r(s);
+        const i32 *it = std::lower_bound(st, st + r, row);
+        if (it == st + r || *it != row) throw std::runtime_error("analyze: entry outside the symbolic structure");
+        return it - st;
+    };
+    // L diagonal first, U diagonal last.  Only the
     //          exact structure is exported; the explicit zeros that amalgamation
     //          added stay inside the panels.
     S.Lp.assign(n + 1, 0);
@@ -1054,7 +1140,6 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
             }
         }
     }
-    S.t_symbolic = seconds_since(t0);
 }
 
 // ----------------------------------------------- general triangular CSC --

@@ -7,6 +7,10 @@ each gets its own handle (its own analysis, HBM state and hipGraph) and its fact
 small pool of streams, so that the per-level launches of different matrices overlap instead of queueing behind each
 other.  torch supplies the streams and the device buffers; the numeric work is the C ABI's.
 """
+import os
+import time
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 import torch
 
@@ -14,12 +18,26 @@ from csparse3_amd import csc_hip
 
 
 class DistinctBatch:
-    """Handles for a list of matrices (m, n, Ap, Ai) with different patterns; analysis on construction."""
+    """Handles for a list of matrices (m, n, Ap, Ai) with different patterns; analysis on construction.
 
-    def __init__(self, patterns, kind=csc_hip.CS3_LU, nstreams=8, device=None):
+    The analyses (ordering + symbolic, host C++ inside the library) are independent and run in a pool of threads: the
+    ctypes call releases the interpreter lock and cs3_analyze keeps no shared state (its error string is per thread), so N
+    patterns cost N / workers analyses of wall time instead of N (analysis_s records it).  workers=1 analyses in line."""
+
+    def __init__(self, patterns, kind=csc_hip.CS3_LU, nstreams=8, device=None, workers=None):
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.kind = kind
-        self.handles = [csc_hip.Factorization(m, n, Ap, Ai, kind=kind) for (m, n, Ap, Ai) in patterns]
+        if workers is None:
+            workers = min(len(patterns), os.cpu_count() or 1, 32)
+        t0 = time.perf_counter()
+        make = lambda p: csc_hip.Factorization(p[0], p[1], p[2], p[3], kind=kind)
+        if workers > 1 and len(patterns) > 1:
+            with ThreadPoolExecutor(max_workers=workers) as pool:
+                self.handles = list(pool.map(make, patterns))           # (results in the order of `patterns`)
+        else:
+            self.handles = [make(p) for p in patterns]
+        self.analysis_s = time.perf_counter() - t0
+        self.workers = workers
         self.n = [int(p[1]) for p in patterns]
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(max(1, min(nstreams, len(patterns))))]
 

@@ -30,6 +30,9 @@ def timed(fn):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / args.reps
 
 out = {"nmat": args.nmat, "n": n5}
+for workers in (1, None):                               # analysis of the distinct patterns: in line, then in the thread pool
+    with DistinctBatch([(mm[0], mm[1], mm[2], mm[3]) for mm in mats], kind=hip.CS3_CHOLESKY, nstreams=1, workers=workers) as D:
+        out["analysis_s_workers_%d" % D.workers] = D.analysis_s
 for ns in (1, args.streams):
     with DistinctBatch([(mm[0], mm[1], mm[2], mm[3]) for mm in mats], kind=hip.CS3_CHOLESKY, nstreams=ns) as D:
         rhs = [torch.from_numpy(b.copy()).to(dev) for b in B]

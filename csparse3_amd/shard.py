@@ -108,16 +108,26 @@ class _Phases:
         self.t0 = now
 
 
-def solve_many_rhs(backend, Ax, B, tol=0.0, group=None, root=0, timings=None, sync=None):
+def solve_many_rhs(backend, Ax, B, tol=0.0, group=None, root=0, timings=None, sync=None, tile=None, resident=False,
+                   gather=True):
     """Config 4: A X = B with B [n, k] known on `root` (a NumPy array, or a torch tensor already in HBM);
     returns X [n, k] on root, None elsewhere.
 
     Collectives: one broadcast of the factor panels, one gather of the solution slabs; the RHS slabs leave the
     root as one batch of point-to-point sends (every xGMI link of the root busy at once).
     `timings` (dict) receives seconds per phase: factor, broadcast, scatter, solve, gather.
+
+    tile (columns): the slabs move and are swept TILE BY TILE -- while a rank sweeps tile t, tile t + 1 of its
+      right-hand sides arrives and tile t - 1 of its solutions leaves (one group of point-to-point operations per stage on
+      both sides, so the pairs always match); the phases "scatter", "solve", "gather" then collapse into "pipeline".
+    resident=True: B is THIS RANK's slab [n, k_r] already in its HBM (right-hand sides generated or assembled in place:
+      SURVEY.md section 8e allows it) -- nothing is scattered; with gather=False the solutions stay sharded too and
+      every rank gets its own slab back, so the only data-path collective is the broadcast of the factors.
     """
     rank, world = (dist.get_rank(group), dist.get_world_size(group)) if world_ready() else (0, 1)
     ph = _Phases(timings, sync)
+    if resident:
+        return _solve_resident_slabs(backend, Ax, B, tol, group, root, ph, gather, rank, world)
     n, k = B.shape if rank == root else (None, None)
     meta = torch.tensor([n or 0, k or 0], dtype=torch.int64)
     if world > 1:
@@ -125,20 +135,9 @@ def solve_many_rhs(backend, Ax, B, tol=0.0, group=None, root=0, timings=None, sy
         dist.broadcast(meta, src=root, group=group)
     n, k = int(meta[0]), int(meta[1])
     # ---- factor once, broadcast the panels
-    if rank == root:
-        backend.factor(Ax, tol)
-        ph.mark("factor")
-        fac = backend.export_factor()
-    else:
-        ph.mark("factor")
-        fac = backend.empty_factor()
-    if world > 1:
-        _settle(fac, group)
-        dist.broadcast(fac, src=root, group=group)
-        _settle(fac, group)
-        if rank != root:
-            backend.import_factor(fac)
-    ph.mark("broadcast")
+    fac = _factor_and_broadcast(backend, Ax, tol, group, root, ph, rank, world)
+    if tile is not None and world > 1:
+        return _pipelined_slabs(backend, B, n, k, int(tile), fac.device, group, root, ph, rank, world)
     # ---- scatter the RHS columns as contiguous slabs [n, k_r]
     lo, hi = shard_range(k, world, rank)
     if world > 1:
@@ -166,6 +165,111 @@ def solve_many_rhs(backend, Ax, B, tol=0.0, group=None, root=0, timings=None, sy
     X = torch.cat(out, dim=1) if rank == root else None
     ph.mark("gather")
     return X
+
+
+def _factor_and_broadcast(backend, Ax, tol, group, root, ph, rank, world):
+    if rank == root:
+        backend.factor(Ax, tol)
+        ph.mark("factor")
+        fac = backend.export_factor()
+    else:
+        ph.mark("factor")
+        fac = backend.empty_factor()
+    if world > 1:
+        _settle(fac, group)
+        dist.broadcast(fac, src=root, group=group)
+        _settle(fac, group)
+        if rank != root:
+            backend.import_factor(fac)
+    ph.mark("broadcast")
+    return fac
+
+
+def _solve_resident_slabs(backend, Ax, B, tol, group, root, ph, gather, rank, world):
+    """solve_many_rhs with the right-hand sides resident per rank: factor on root, broadcast, sweep the local slab."""
+    _factor_and_broadcast(backend, Ax, tol, group, root, ph, rank, world)
+    mine = backend.to_device(B).contiguous()
+    if isinstance(B, torch.Tensor) and mine.data_ptr() == B.data_ptr():
+        mine = mine.clone()
+    ph.mark("scatter")
+    if mine.shape[-1] > 0:
+        backend.solve(mine)
+    ph.mark("solve")
+    if world == 1 or not gather:
+        ph.mark("gather")
+        return mine
+    widths = torch.tensor([mine.shape[1]], dtype=torch.int64, device=_comm_device(backend))
+    allw = [torch.zeros_like(widths) for _ in range(world)]
+    dist.all_gather(allw, widths, group=group)
+    out = _gather_uneven(mine, [(mine.shape[0], int(w[0])) for w in allw], root, group)
+    X = torch.cat(out, dim=1) if rank == root else None
+    ph.mark("gather")
+    return X
+
+
+def _pipelined_slabs(backend, B, n, k, tile, dev, group, root, ph, rank, world):
+    """Scatter -> sweep -> gather of solve_many_rhs, tile by tile.  Stage s = one group of point-to-point operations
+    {right-hand sides of tile s + 1 root -> peers, solutions of tile s - 1 peers -> root} posted before the sweep of tile s
+    and waited for after it: with RCCL the group runs on the communicator's stream beside the sweep.  Every rank derives
+    the same tile shapes from (k, world, tile), so both sides of a pair always post the same stages."""
+    ranges = [shard_range(k, world, r) for r in range(world)]
+    tiles = [[(lo + t, min(lo + t + tile, hi)) for t in range(0, hi - lo, tile)] for lo, hi in ranges]
+    nstage = max(len(t) for t in tiles)
+    Bd = backend.to_device(B) if rank == root else None
+    mine = tiles[rank]
+    bufs = [torch.empty((n, c1 - c0), dtype=torch.float64, device=dev) for c0, c1 in mine]
+    # root: solutions of the peers' tiles as they arrive
+    xbuf = {(r, t): torch.empty((n, c1 - c0), dtype=torch.float64, device=dev)
+            for r in range(world) if rank == root and r != root for t, (c0, c1) in enumerate(tiles[r])}
+    keep = []                                       # send buffers stay alive until their stage has been waited for
+
+    def stage_ops(s):
+        ops = []
+        if rank == root:
+            for r in range(world):
+                if r == root:
+                    continue
+                if s + 1 < len(tiles[r]):           # right-hand sides of tile s + 1 of rank r
+                    c0, c1 = tiles[r][s + 1]
+                    t_ = Bd[:, c0:c1].contiguous()
+                    keep.append(t_)
+                    ops.append(dist.P2POp(dist.isend, t_, r, group))
+                if 0 <= s - 1 < len(tiles[r]):      # solutions of its tile s - 1
+                    ops.append(dist.P2POp(dist.irecv, xbuf[(r, s - 1)], r, group))
+        else:
+            if s + 1 < len(mine):
+                ops.append(dist.P2POp(dist.irecv, bufs[s + 1], root, group))
+            if 0 <= s - 1 < len(mine):
+                ops.append(dist.P2POp(dist.isend, bufs[s - 1], root, group))
+        return ops
+
+    def post(s):
+        ops = stage_ops(s)
+        _settle(bufs[0] if bufs else None, group)
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def wait(reqs):
+        for q in reqs:
+            q.wait()
+        _settle(bufs[0] if bufs else None, group)
+
+    wait(post(-1))                                  # tile 0 of every peer
+    for s in range(nstage):
+        if rank == root and s < len(mine):
+            c0, c1 = mine[s]
+            bufs[s].copy_(Bd[:, c0:c1])
+        reqs = post(s)
+        if s < len(mine):
+            backend.solve(bufs[s])
+        wait(reqs)
+    wait(post(nstage))                              # the last tile's solutions
+    ph.mark("pipeline")
+    if rank != root:
+        return None
+    cols = []
+    for r in range(world):
+        cols += bufs if r == root else [xbuf[(r, t)] for t in range(len(tiles[r]))]
+    return torch.cat(cols, dim=1) if cols else torch.empty((n, 0), dtype=torch.float64, device=dev)
 
 
 def world_ready():

@@ -74,8 +74,21 @@ def _worker(rank, world, port, mode, out):
             X = shard.solve_many_rhs(be, Ax if rank == 0 else None, B if rank == 0 else None, tol=1e-3,
                                      timings=tm, sync=dist.barrier)
             assert set(tm) == {"factor", "broadcast", "scatter", "solve", "gather"} and all(v >= 0.0 for v in tm.values())
+            # the same tile by tile (tiles of 2 columns: 2 + 2 on rank 0, 2 + 1 on rank 1) ...
+            tm2 = {}
+            Xt = shard.solve_many_rhs(be, Ax if rank == 0 else None, B.copy() if rank == 0 else None, tol=1e-3, tile=2,
+                                      timings=tm2, sync=dist.barrier)
+            assert set(tm2) == {"factor", "broadcast", "pipeline"}
+            # ... and with the right-hand sides resident per rank (every rank cuts its own slab), gathered or left sharded
+            lo, hi = shard.shard_range(7, world, rank)
+            Xr = shard.solve_many_rhs(be, Ax if rank == 0 else None, B[:, lo:hi].copy(), tol=1e-3, resident=True)
+            Xs = shard.solve_many_rhs(be, Ax if rank == 0 else None, B[:, lo:hi].copy(), tol=1e-3, resident=True, gather=False)
+            assert Xs.shape == (n, hi - lo)
             if rank == 0:
+                assert torch.equal(X, Xt) and torch.equal(X, Xr) and torch.equal(X[:, lo:hi], Xs)
                 np.save(out, X.numpy())
+            else:
+                assert Xt is None and Xr is None
         else:
             n = 300
             ei, ej = synth.spd_grid_pattern(n, seed=5)
@@ -187,6 +200,75 @@ def test_two_ranks_gloo_on_one_gpu(gpu, tmp_path, mode):
             m, n, Ap, Ai, Ax = synth.spd_grid_matrix(n, ei, ej, seed=50 + i)
             A = sp.csc_matrix((Ax, Ai, Ap), shape=(n, n))
             assert np.abs(A @ X[i] - B[i]).max() <= 1e-10 * np.abs(B[i]).max()
+
+
+def _gpu_worker_full(rank, world, port, mode, out):
+    """Two ranks sharing cuda:0 at the shapes BASELINE.json quotes for the sharded configurations: 50 000 x 1024 right-hand
+    sides split 512 / 512 (tile-pipelined, then resident per rank), 512 matrices of 5000 columns split 256 / 256."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        if mode == "rhs":
+            m, n, Ap, Ai, Ax = synth.grid_jacobian()
+            k = 1024
+            B = synth.grid_rhs(n, k)
+            be = shard.HipBackend(m, n, Ap, Ai, device=dev)
+            X = shard.solve_many_rhs(be, Ax if rank == 0 else None, B if rank == 0 else None, tol=1e-3, tile=128)
+            lo, hi = shard.shard_range(k, world, rank)
+            Xs = shard.solve_many_rhs(be, Ax if rank == 0 else None, torch.from_numpy(B[:, lo:hi].copy()).to(dev), tol=1e-3,
+                                      resident=True, gather=False)
+            cols = [0, 127, 128, 511, 512, 640, 1023]
+            if rank == 0:
+                assert X.shape == (n, k)
+                np.savez(out, X=X[:, cols].cpu().numpy(), Xs=Xs[:, [c for c in cols if c < hi]].cpu().numpy())
+            else:
+                np.savez(out + ".rank1", Xs=Xs[:, [c - lo for c in cols if c >= lo]].cpu().numpy())
+        else:
+            from csparse3_amd import csc_hip
+            n, nmat = 5000, 512
+            ei, ej = synth.spd_grid_pattern(n, seed=5000)
+            m, n, Ap, Ai, _ = synth.spd_grid_matrix(n, ei, ej, seed=5000)
+            lo, hi = shard.shard_range(nmat, world, rank)
+            AX = np.stack([synth.spd_grid_matrix(n, ei, ej, seed=5000 + i)[4] for i in range(lo, hi)])
+            B = np.random.default_rng(1).standard_normal((nmat, n, 1))
+            X = shard.solve_many_matrices(lambda b: shard.HipBackend(m, n, Ap, Ai, kind=csc_hip.CS3_CHOLESKY, batch=b, device=dev),
+                                          AX, B, tol=0.0, local_values=True, total=nmat)
+            if rank == 0:
+                assert X.shape == (nmat, n, 1)
+                np.save(out, X[[0, 63, 64, 255, 256, 300, 511]].cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["rhs", "matrices"])
+def test_two_ranks_at_the_configurations_own_shapes(gpu, tmp_path, mode):
+    """the 2-rank path at config 4's and config 5's OWN shapes, real backend, one GPU, gloo."""
+    import scipy.sparse as sp
+    out = str(tmp_path / ("x.npz" if mode == "rhs" else "x.npy"))
+    mp.spawn(_gpu_worker_full, args=(2, _free_port(), mode, out), nprocs=2, join=True)
+    if mode == "rhs":
+        m, n, Ap, Ai, Ax = synth.grid_jacobian()
+        B = synth.grid_rhs(n, 1024)
+        A = sp.csc_matrix((Ax, Ai, Ap), shape=(n, n))
+        cols = [0, 127, 128, 511, 512, 640, 1023]
+        got = np.load(out)
+        X = got["X"]
+        assert np.abs(A @ X - B[:, cols]).max() <= 1e-10 * np.abs(B).max()
+        Xs = np.concatenate([got["Xs"], np.load(out + ".rank1.npz")["Xs"]], axis=1)      # the resident slabs, left sharded
+        assert np.array_equal(Xs, X)
+    else:
+        n = 5000
+        ei, ej = synth.spd_grid_pattern(n, seed=5000)
+        B = np.random.default_rng(1).standard_normal((512, n, 1))
+        X = np.load(out)
+        for j, i in enumerate([0, 63, 64, 255, 256, 300, 511]):
+            m, n, Ap, Ai, Ax = synth.spd_grid_matrix(n, ei, ej, seed=5000 + i)
+            A = sp.csc_matrix((Ax, Ai, Ap), shape=(n, n))
+            A = A + sp.tril(A, -1).T if (sp.triu(A, 1).nnz == 0) else A
+            assert np.abs(A @ X[j] - B[i]).max() <= 1e-10 * np.abs(B[i]).max()
 
 
 @pytest.mark.gpu

@@ -195,6 +195,23 @@ def leg_config4(args, dist, rank, world, dev, comm_dev, host_baseline):
     keys = ["factor", "broadcast", "scatter", "solve", "gather", "total"]
     med = [float(np.median([p.get(kk, 0.0) for p in phases])) for kk in keys]
     med = _max_over_ranks(dist, world, comm_dev, med)
+    # N > 1: the same job with the slabs moved and swept tile by tile (scatter, sweep and gather overlapped), and with the
+    # right-hand sides resident per rank and the solutions left sharded (only the factor broadcast crosses xGMI)
+    variants = {}
+    if world > 1:
+        lo, hi = shard.shard_range(k, world, rank)
+        slab = torch.from_numpy(np.ascontiguousarray(synth.grid_rhs(n, k, seed=1024)[:, lo:hi])).to(dev)
+        for name, kw in (("pipelined_tiles_of_128", dict(tile=128)), ("resident_slabs_sharded_solution", dict(resident=True, gather=False))):
+            ts = []
+            for it in range(reps + 1):
+                _sync(dist, world)
+                t0 = time.perf_counter()
+                shard.solve_many_rhs(be, Ax, slab if "resident" in kw else Bd, tol=1e-3, **kw)
+                _sync(dist, world)
+                if it > 0:
+                    ts.append(time.perf_counter() - t0)
+            variants[name] = 1e3 * _max_over_ranks(dist, world, comm_dev, [float(np.median(ts))])[0]
+        del slab
     # one GPU: the same sweep bracketed by HIP events on the launch stream (the phase above is host wall-clock between
     # two device synchronisations: it carries the graph launch and the wake-up of the host, 50-90 us)
     solve_ms_events = None
@@ -232,6 +249,8 @@ def leg_config4(args, dist, rank, world, dev, comm_dev, host_baseline):
                "frac_note": "solve phase: algorithmic bytes / max-over-ranks solve time / (n_gpus x 8 TB/s)",
                "factor_bytes_broadcast": int(info.factor_bytes),
                "rel_residual": rel}
+        if variants:
+            out["variants_total_ms"] = variants          # total job time (factor + broadcast + everything) of each variant
         if solve_ms_events is not None:
             out["solve_ms_events"] = solve_ms_events
             out["frac_events"] = bytes_solve / (1e-3 * solve_ms_events) / 1e9 / HBM_PEAK_GBS

@@ -93,7 +93,7 @@ void release_device(cs3_handle h)
     drop_solve_graphs(h);
     if (h->cap_stream) { (void) hipStreamDestroy(h->cap_stream); h->cap_stream = nullptr; }
     h->fj.destroy();
-    void **ptrs[] = {(void **) &D.fdesc, (void **) &D.st_idx, (void **) &D.asm_src, (void **) &D.asm_tgt, (void **) &D.long_src,
+    void **ptrs[] = {(void **) &D.fdesc, (void **) &D.st_idx, (void **) &D.fa_tgt, (void **) &D.fa_src, (void **) &D.ch_tab, (void **) &D.rel_idx,
                      (void **) &D.sdesc, (void **) &D.sdesc1, (void **) &D.sub_tasks, (void **) &D.sub_fronts, (void **) &D.sub_lvl,
                      (void **) &D.sub_rel, (void **) &D.sub_st, (void **) &D.sub_child, (void **) &D.sub_a_tgt, (void **) &D.sub_a_src,
                      (void **) &D.axf, (void **) &D.fasm_src, (void **) &D.fasm_tgt, (void **) &D.flong_src, (void **) &D.rl_pairs,
@@ -162,8 +162,9 @@ int ensure_device_impl(cs3_handle h)
         const i32 s = S.sched[t];
         FrontDesc &f = fdesc[t];
         f.lpan = S.lpan_off[s]; f.upan = S.upan_off[s]; f.cb = S.cb_off[s];
-        f.asm_begin = S.asm_ptr[s]; f.asm_count = (int) (S.asm_ptr[s + 1] - S.asm_ptr[s]);
-        if (S.sn_class[s] == FC_IL) { f.asm_begin = S.ila_ptr[s]; f.asm_count = (int) (S.ila_ptr[s + 1] - S.ila_ptr[s]); }
+        f.a_begin = S.fa_ptr[s]; f.a_count = (int) (S.fa_ptr[s + 1] - S.fa_ptr[s]);
+        f.ch_begin = (int) S.ch_ptr[s]; f.ch_count = (int) (S.ch_ptr[s + 1] - S.ch_ptr[s]);
+        if (S.sn_class[s] == FC_IL) { f.a_begin = S.ila_ptr[s]; f.a_count = (int) (S.ila_ptr[s + 1] - S.ila_ptr[s]); }
         f.c0 = S.sn_ptr[s];
         f.r = (int) (S.st_ptr[s + 1] - S.st_ptr[s]);
         f.w = S.sn_ptr[s + 1] - S.sn_ptr[s];
@@ -202,9 +203,14 @@ int ensure_device_impl(cs3_handle h)
     if ((rc = upload(&D.sl_src, S.sl_src))) return rc;
     if ((rc = upload(&D.fdesc, fdesc))) return rc;
     if ((rc = upload(&D.st_idx, S.st_idx))) return rc;
-    if ((rc = upload(&D.asm_src, S.asm_src))) return rc;
-    if ((rc = upload(&D.asm_tgt, S.asm_tgt))) return rc;
-    if ((rc = upload(&D.long_src, S.long_src))) return rc;
+    if ((rc = upload(&D.fa_tgt, S.fa_tgt))) return rc;
+    if ((rc = upload(&D.fa_src, S.fa_src))) return rc;
+    {
+        std::vector<i32> tab(S.ch_tab);
+        tab.resize(tab.size() + 4, 0);                          // (16-byte loads of the last entry stay inside the array)
+        if ((rc = upload(&D.ch_tab, tab))) return rc;
+    }
+    if ((rc = upload(&D.rel_idx, S.rel_idx))) return rc;
     if ((rc = upload(&D.q, S.q))) return rc;
     if ((rc = upload(&D.ila_pairs, S.ila_pairs))) return rc;
     if ((rc = upload(&D.inv_tasks, S.inv_tasks))) return rc;

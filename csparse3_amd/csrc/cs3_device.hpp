@@ -12,9 +12,10 @@ namespace cs3 {
 // so that block b of a launch group reads entry first + b with no indirection.
 struct FrontDesc {
     long long lpan, upan, cb;     // pool offsets: L panel (ld r), U panel, contribution block
-    long long asm_begin;          // first entry of the assembly list
+    long long a_begin;            // first of its entries of A in fa_tgt / fa_src (FC_IL fronts: first pair in ila_pairs)
     long long dbuf;               // big fronts: parked diagonal blocks, BIG_NB^2 doubles per block step
-    int asm_count;                // entries in it (multiple of 64)
+    int a_count;                  // ... and how many
+    int ch_begin, ch_count;       // its children in ch_tab (4 ints each)
     int c0, r, w;
     int cb_ld, u_sk, u_sj;
     int parent;
@@ -57,7 +58,7 @@ struct DeviceFactor {
     bool zero_big = true;         //   ... by the prologue, unless every big front runs in k_front_wg (which zeroes its own)
     FrontDesc *fdesc = nullptr;
     int *st_idx = nullptr;        // row structures (backward sweep: rows of the ancestors)
-    int *asm_src = nullptr, *asm_tgt = nullptr, *long_src = nullptr;
+    int *fa_tgt = nullptr, *fa_src = nullptr, *ch_tab = nullptr, *rel_idx = nullptr;   // assembly: entries of A, children tables, row maps
     SolveDesc *sdesc = nullptr;
     // one right-hand side with a bottom forest: descriptors in the order of Symbolic::ssched1; sd_active is what the sweep
     // launchers hand to the kernels (set by the caller together with the launch groups it passes: sdesc or sdesc1)
@@ -100,6 +101,13 @@ struct DeviceFactor {
     long long nrhs_cap = 0;
     int *status = nullptr;        // [0] first failing pivot column, 0x7f7f7f7f when clean; [3]: a hand-over between waves timed out
     long long *tbuf = nullptr;    // diagnostics (CS3_PROFILE=1): 8 shader-clock stamps per front, schedule order
+};
+
+// What the assembly of a front reads, as a kernel argument (by value).
+struct AsmLists {
+    const int *fa_tgt, *fa_src;   // entries of A: target in the front (image index / pool offset), entry of Ax
+    const int *ch_tab;            // children: update rows, row map (first entry in rel_idx), block offset, leading dimension
+    const int *rel_idx;
 };
 
 // The interleaved block as a kernel argument (by value).

@@ -52,7 +52,6 @@ struct LaunchGroup {          // fronts of one level that share a kernel configu
     i32 first, count;         // range in Symbolic::sched
     i32 max_r;                // largest front order in the group (sizes dynamic LDS)
     i32 max_w;                // widest supernode in the group (block steps of the big path)
-    i64 max_asm;              // longest assembly list in the group
     i32 n16 = 0;              // solve groups: leading fronts of order <= 16 (sorted first: a leaner kernel instance takes them)
 };
 
@@ -134,13 +133,11 @@ struct Symbolic {
     std::vector<i32> ila_pairs;               // (front-local target, source) sorted by target; EVERY stored entry of the
                                               //   front appears: source >= 0 pool offset, < 0 entry ~src of Ax, IL_ZERO none
     i64 big_begin = 0;                        // big-front buffers occupy [big_begin, vals_size)
-    // assembly: every front entry = sum of its sources (A entries, children's
-    // contribution blocks), listed sorted by target.  src >= 0: pool offset;
-    // src < 0: entry ~src of Ax.  Runs (equal targets) never straddle a
-    // 64-entry boundary; padding entries carry target ASM_DUMMY.
-    std::vector<i64> asm_ptr;                 // [nsuper+1]
-    std::vector<i32> asm_src, asm_tgt;
-    std::vector<i32> long_src;                // sources of runs longer than 64
+    // assembly of the level kernels' fronts (symbolic.cpp, step 9): entries of A as (target, entry of Ax) per front, and a
+    // table of children (4 ints each: update rows, first entry of the row map in rel_idx, pool offset and leading
+    // dimension of the contribution block) -- the kernels extend-add the blocks through the row maps
+    std::vector<i64> fa_ptr, ch_ptr;          // [nsuper+1]
+    std::vector<i32> fa_tgt, fa_src, ch_tab;
     // forward solve: front vector entry = sum of its sources, same encoding
     // (src >= 0: entry of the contribution-vector pool; src < 0: row ~src of X)
     std::vector<i64> fasm_ptr;

@@ -121,6 +121,92 @@ __device__ __forceinline__ void gather_front(long long asm_begin, int nchunks, i
     }
 }
 
+// ------------------------------------------------ assembly by extend-add --
+// The factor kernels assemble a front from (i) its entries of A, scattered into the zeroed front, and (ii) its children's
+// contribution blocks, added THROUGH THEIR ROW MAPS: F(rel[i], rel[j]) += C(i, j), children in order, a barrier between
+// two children (they may meet in an entry; inside one child every entry has a target of its own).  The blocks are read
+// column by column, coalesced, and the only index data is one row map of nbc entries per child -- round 1 and 2 read a
+// sorted (target, source) list, 8 bytes of index per 8 bytes of value, and summed runs of equal targets with shuffles.
+// The order of the additions is fixed, so results stay bitwise reproducible.
+//   put(t, v)        stores an entry of A at the target the analysis computed (image index or pool offset)
+//   acc(i, j, v)     adds v to entry (i, j) of the front
+//   sync()           barrier of the threads that assemble this front together (nth of them, thread `tid`)
+// F += v without reading F back: the hardware's f64 add (ds_add_f64 / global_atomic_add_f64, no return value).  Inside one
+// child of an extend-add every entry has one source, and two children are separated by a barrier: the ORDER of the
+// additions to an entry is fixed, atomic or not -- what the instruction saves is the load, the wait and the store.
+__device__ __forceinline__ void front_add(double *p, double v) { unsafeAtomicAdd(p, v); }
+
+template <int KIND, class Put, class Acc, class Sync>
+__device__ __forceinline__ void assemble_extend_add(const FrontDesc &d, const AsmLists &al, const double *__restrict__ ax,
+                                                    const double *__restrict__ pool, const double *__restrict__ pil, long long il_len,
+                                                    int tid, int nth, Put put, Acc acc, Sync sync)
+{
+    for (int e = tid; e < d.a_count; e += nth) {
+        const long long idx = d.a_begin + e;
+        put(al.fa_tgt[idx], ax[al.fa_src[idx]]);
+    }
+    sync();
+    const int lane = tid & 63, wv = tid >> 6, nw = nth >> 6;
+    const int4 *tab = (const int4 *) al.ch_tab + d.ch_begin;
+    for (int c = 0; c < d.ch_count; ++c) {
+        const int4 ce = tab[c];
+        const int nbc = ce.x, cbo = ce.z, cld = ce.w;
+        const int *__restrict__ rel = al.rel_idx + ce.y;
+        const bool il = cbo < il_len;                            // a block in the matrix-interleaved region (large batches)
+        // (four entries per thread and pass: their loads go out together -- one entry at a time every pass waited out a
+        //  round trip to the block, and a batch of 512 matrices ran 10 % slower than through the gather lists)
+        constexpr int EU = 4;
+        if (nbc <= 32) {                                         // two columns of the block per wave and step
+            const int ii = lane & 31, slots = nth >> 5;
+            const bool mine = ii < nbc;
+            const int myrel = rel[mine ? ii : 0];
+            for (int j0 = tid >> 5; j0 < nbc; j0 += EU * slots) {
+                double v[EU];
+                int cj[EU];
+                bool on[EU];
+#pragma unroll
+                for (int u = 0; u < EU; ++u) {
+                    const int jj = j0 + u * slots;
+                    on[u] = mine && jj < nbc && (KIND == CS3_LU || ii >= jj);
+                    const long long off = on[u] ? cbo + ii + (long long) jj * cld : cbo;
+                    v[u] = il ? pil[off * 64] : pool[off];
+                    cj[u] = rel[jj < nbc ? jj : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < EU; ++u)
+                    if (on[u]) acc(myrel, cj[u], v[u]);
+            }
+        } else {
+            // the block's entries dealt to the threads one after the other (rows fastest: coalesced), so that every
+            // lane has work whatever the block's order; e -> (row, column) by a float reciprocal and two corrections
+            const int total = nbc * nbc;
+            const float inv = 1.0f / (float) nbc;
+            for (int e0 = tid; e0 < total; e0 += EU * nth) {
+                double v[EU];
+                int ri[EU], cj[EU];
+                bool on[EU];
+#pragma unroll
+                for (int u = 0; u < EU; ++u) {
+                    const int e = e0 + u * nth;
+                    int jj = (int) ((float) e * inv);
+                    jj += ((jj + 1) * nbc <= e) ? 1 : 0;
+                    jj -= (jj * nbc > e) ? 1 : 0;
+                    const int ii = e - jj * nbc;
+                    on[u] = e < total && (KIND == CS3_LU || ii >= jj);
+                    const long long off = on[u] ? cbo + ii + (long long) jj * cld : cbo;
+                    v[u] = il ? pil[off * 64] : pool[off];
+                    ri[u] = rel[on[u] ? ii : 0];
+                    cj[u] = rel[on[u] ? jj : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < EU; ++u)
+                    if (on[u]) acc(ri[u], cj[u], v[u]);
+            }
+        }
+        sync();
+    }
+}
+
 // The same gather for NV values per source (NV right-hand sides, contiguous in memory):
 // fetch(s) returns the address of value 0 of source s, nlive of the NV are real.
 template <int NV, class Fetch, class Store>
@@ -174,7 +260,7 @@ __device__ __forceinline__ void gather_front_vec(long long asm_begin, int nchunk
 template <int KIND, int THREADS, int TX, int RI, int RJ>
 __device__ __forceinline__ void
 front_lds_body(const FrontDesc &d, int first, double *F,
-               const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
+               AsmLists al,
                const double *__restrict__ ax_all, double *__restrict__ pool_all,
                long long nnz_a, long long pool_stride, IlView il, double inv_tol, int *status, long long *tbuf, long long t_start)
 {
@@ -193,11 +279,10 @@ front_lds_body(const FrontDesc &d, int first, double *F,
     for (int i = tid; i < r * ld; i += THREADS) F[i] = 0.0;
     __syncthreads();
     CS3_STAMP(1);
-    gather_front(d.asm_begin, d.asm_count >> 6, tid >> 6, THREADS / 64,
-                 asm_src, asm_tgt, long_src,
-                 [&](int q) -> const double * { return (q >= 0) ? ((q < il.len) ? pil + (long long) q * 64 : pool + q) : ax + ~q; },
-                 [&](int t, double v) { F[t] = v; });
-    __syncthreads();
+    assemble_extend_add<KIND>(d, al, ax, pool, pil, il.len, tid, THREADS,
+                              [&](int t, double v) { F[t] = v; },
+                              [&](int i, int j, double v) { front_add(&F[i + j * ld], v); },
+                              [&]() { __syncthreads(); });
     CS3_STAMP(2);
 
     // ---- my entries into registers
@@ -448,7 +533,7 @@ __device__ __forceinline__ void eliminate_parts(double (&d)[PAIR_NC], int part, 
 template <int KIND, int NC>
 __device__ __forceinline__ void
 front_wave_body(const FrontDesc &d, int first, double *F,
-                const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
+                AsmLists al,
                 const double *__restrict__ ax_all, double *__restrict__ pool_all,
                 long long nnz_a, long long pool_stride, IlView il, double inv_tol, int *status, long long *tbuf, long long t_start)
 {
@@ -468,11 +553,10 @@ front_wave_body(const FrontDesc &d, int first, double *F,
     if (threadIdx.x == 0 && blockDim.x > 64) *(int *) (F + r * ld + 2) = 0;                     // eliminate_parts' counter
     __syncthreads();
     CS3_STAMP(1);
-    gather_front(d.asm_begin, d.asm_count >> 6, threadIdx.x >> 6, nwaves,
-                 asm_src, asm_tgt, long_src,
-                 [&](int q) -> const double * { return (q >= 0) ? ((q < il.len) ? pil + (long long) q * 64 : pool + q) : ax + ~q; },
-                 [&](int t, double v) { F[t] = v; });
-    __syncthreads();
+    assemble_extend_add<KIND>(d, al, ax, pool, pil, il.len, (int) threadIdx.x, (int) blockDim.x,
+                              [&](int t, double v) { F[t] = v; },
+                              [&](int i, int j, double v) { front_add(&F[i + j * ld], v); },
+                              [&]() { __syncthreads(); });
     CS3_STAMP(2);
     const bool coop = blockDim.x > 64;          // helper waves stay for the store pass
     if (threadIdx.x >= 64 && !coop) return;
@@ -630,14 +714,14 @@ front_wave_body(const FrontDesc &d, int first, double *F,
 template <int KIND>
 __global__ void __launch_bounds__(64)
 k_front_wave(const FrontDesc *__restrict__ fdesc, int first,
-             const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
+             AsmLists al,
              const double *__restrict__ ax_all, double *__restrict__ pool_all,
              long long nnz_a, long long pool_stride, IlView il, double inv_tol, int *status, long long *tbuf)
 {
     extern __shared__ __attribute__((aligned(16))) double F[];
     const long long t_start = tbuf ? (long long) __builtin_amdgcn_s_memtime() : 0;
     const FrontDesc d = fdesc[first + blockIdx.x];
-    front_wave_body<KIND, 32>(d, first, F, asm_src, asm_tgt, long_src, ax_all, pool_all, nnz_a, pool_stride, il,
+    front_wave_body<KIND, 32>(d, first, F, al, ax_all, pool_all, nnz_a, pool_stride, il,
                               inv_tol, status, tbuf, t_start);
 }
 
@@ -646,7 +730,7 @@ k_front_wave(const FrontDesc *__restrict__ fdesc, int first,
 template <int KIND>
 __global__ void __launch_bounds__(256)
 k_front_mix(const FrontDesc *__restrict__ fdesc, int first,
-            const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
+            AsmLists al,
             const double *__restrict__ ax_all, double *__restrict__ pool_all,
             long long nnz_a, long long pool_stride, IlView il, double inv_tol, int *status, long long *tbuf)
 {
@@ -654,10 +738,10 @@ k_front_mix(const FrontDesc *__restrict__ fdesc, int first,
     const long long t_start = tbuf ? (long long) __builtin_amdgcn_s_memtime() : 0;
     const FrontDesc d = fdesc[first + blockIdx.x];
     if (d.r <= 32)                      // (four waves gather, two share the elimination)
-        front_wave_body<KIND, 32>(d, first, F, asm_src, asm_tgt, long_src, ax_all, pool_all, nnz_a, pool_stride, il,
+        front_wave_body<KIND, 32>(d, first, F, al, ax_all, pool_all, nnz_a, pool_stride, il,
                                   inv_tol, status, tbuf, t_start);
     else
-        front_lds_body<KIND, 256, 16, 4, 4>(d, first, F, asm_src, asm_tgt, long_src, ax_all, pool_all, nnz_a,
+        front_lds_body<KIND, 256, 16, 4, 4>(d, first, F, al, ax_all, pool_all, nnz_a,
                                             pool_stride, il, inv_tol, status, tbuf, t_start);
 }
 
@@ -670,20 +754,57 @@ constexpr int BIG_NB = 32;
 static_assert(BIG_NB == 2 * PAIR_NC, "eliminate_pair splits a block of BIG_NB pivots in two");
 
 __global__ void __launch_bounds__(256)
-k_big_gather(const FrontDesc *__restrict__ fdesc, int first,
-             const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
+k_big_gather(const FrontDesc *__restrict__ fdesc, int first, int kind,
+             AsmLists al,
              const double *__restrict__ ax_all, double *__restrict__ pool_all,
              long long nnz_a, long long pool_stride, IlView il)
 {
+    // Several workgroups assemble one front: workgroup b OWNS a block of the front's columns, so that no two of them ever
+    // touch the same entry and the children can still be added in order with block barriers only.  A child's columns that
+    // land in my block are a contiguous range of its row map (the map ascends).
     const FrontDesc d = fdesc[first + blockIdx.z];
     const double *pil = il_lane_base(il, blockIdx.y);
     const double *ax = ax_all + (long long) blockIdx.y * nnz_a;
     double *pool = pool_all + (long long) blockIdx.y * pool_stride;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    gather_front(d.asm_begin, d.asm_count >> 6, wave, gridDim.x * 4,
-                 asm_src, asm_tgt, long_src,
-                 [&](int q) -> const double * { return (q >= 0) ? ((q < il.len) ? pil + (long long) q * 64 : pool + q) : ax + ~q; },
-                 [&](int t, double v) { pool[t] = v; });
+    const int r = d.r;
+    const int cw = (r + (int) gridDim.x - 1) / (int) gridDim.x, c_lo = (int) blockIdx.x * cw, c_hi = min(r, c_lo + cw);
+    if (c_lo >= r) return;
+    double *F = pool + d.lpan;                       // dense r x r, leading dimension r (zeroed by the prologue)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float inv_r = 1.0f / (float) r;
+    for (int e = tid; e < d.a_count; e += 256) {
+        const long long idx = d.a_begin + e;
+        const int t = al.fa_tgt[idx], rel_t = t - (int) d.lpan;
+        int col = (int) ((float) rel_t * inv_r);     // t = lpan + row + col r: unpack (exact after the two corrections)
+        col += ((long long) (col + 1) * r <= rel_t) ? 1 : 0;
+        col -= ((long long) col * r > rel_t) ? 1 : 0;
+        if (col >= c_lo && col < c_hi) pool[t] = ax[al.fa_src[idx]];
+    }
+    __syncthreads();
+    const int4 *tab = (const int4 *) al.ch_tab + d.ch_begin;
+    for (int c = 0; c < d.ch_count; ++c) {
+        const int4 ce = tab[c];
+        const int nbc = ce.x, cbo = ce.z, cld = ce.w;
+        const int *__restrict__ rel = al.rel_idx + ce.y;
+        const bool inter = cbo < il.len;
+        // first child column at or beyond c_lo / c_hi (binary searches, the same in every thread)
+        auto first_at = [&](int from, int bound) {
+            int lo = from, hi = nbc;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (rel[mid] < bound) lo = mid + 1; else hi = mid; }
+            return lo;
+        };
+        const int j0 = first_at(0, c_lo), j1 = first_at(j0, c_hi);
+        for (int jj = j0 + wv; jj < j1; jj += 4) {
+            const long long cj = (long long) rel[jj] * r;
+            for (int ii = lane; ii < nbc; ii += 64) {
+                if (kind == CS3_LU || ii >= jj) {
+                    const long long off = cbo + ii + (long long) jj * cld;
+                    front_add(&F[rel[ii] + cj], inter ? pil[off * 64] : pool[off]);
+                }
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // Unblocked LU / Cholesky of a 32 x 32 block by ONE wave without barriers, with a panel solve for
@@ -758,7 +879,7 @@ __device__ __forceinline__ void eliminate32(double (&d)[BIG_NB], bool keep_unsca
 template <int KIND, int NBK, int NW = 8>
 __global__ void __launch_bounds__(NW * 64)
 k_front_block(const FrontDesc *__restrict__ fdesc, int first,
-              const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
+              AsmLists al,
               const double *__restrict__ ax_all, double *__restrict__ pool_all,
               long long nnz_a, long long pool_stride, IlView il, double inv_tol, int *status, long long *tbuf)
 {
@@ -786,16 +907,16 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
     __syncthreads();
     CS3_STAMP(1);
     const float inv_ld = 1.0f / (float) ld;
-    gather_front<GATHER_UNROLL_WG>(d.asm_begin, d.asm_count >> 6, wv, NW, asm_src, asm_tgt, long_src,
-                 [&](int q) -> const double * { return (q >= 0) ? ((q < il.len) ? pil + (long long) q * 64 : pool + q) : ax + ~q; },
-                 [&](int t, double v) {
-                     if (KIND == CS3_LU) { F[t] = v; return; }
-                     int j = (int) ((float) t * inv_ld);            // the list's targets are i + j ld: unpack (t < 2^15)
-                     j += ((j + 1) * ld <= t) ? 1 : 0;
-                     j -= (j * ld > t) ? 1 : 0;
-                     F[at(t - j * ld, j)] = v;
-                 });
-    __syncthreads();
+    assemble_extend_add<KIND>(d, al, ax, pool, pil, il.len, tid, NW * 64,
+                              [&](int t, double v) {
+                                  if (KIND == CS3_LU) { F[t] = v; return; }
+                                  int j = (int) ((float) t * inv_ld);       // the targets of A's entries are i + j ld: unpack (t < 2^15)
+                                  j += ((j + 1) * ld <= t) ? 1 : 0;
+                                  j -= (j * ld > t) ? 1 : 0;
+                                  F[at(t - j * ld, j)] = v;
+                              },
+                              [&](int i, int j, double v) { front_add(&F[at(i, j)], v); },
+                              [&]() { __syncthreads(); });
     CS3_STAMP(2);
 
     bool bad = false;
@@ -931,7 +1052,7 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
 template <int KIND, int NB>
 __global__ void __launch_bounds__(512, (NB <= 16) ? 4 : 2)
 k_front_wg(const FrontDesc *__restrict__ fdesc, int first,
-           const int *__restrict__ asm_src, const int *__restrict__ asm_tgt, const int *__restrict__ long_src,
+           AsmLists al,
            const double *__restrict__ ax_all, double *__restrict__ pool_all,
            long long nnz_a, long long pool_stride, IlView il, double inv_tol, int *status, int pld, long long *tbuf)
 {
@@ -959,10 +1080,10 @@ k_front_wg(const FrontDesc *__restrict__ fdesc, int first,
     for (long long e = tid; e < (long long) r * r; e += 512) F[e] = 0.0;
     __syncthreads();
     CS3_WSTAMP(0);
-    gather_front<GATHER_UNROLL_BIG>(d.asm_begin, d.asm_count >> 6, wv, 8, asm_src, asm_tgt, long_src,
-                 [&](int q) -> const double * { return (q >= 0) ? ((q < il.len) ? pil + (long long) q * 64 : pool + q) : ax + ~q; },
-                 [&](int t, double v) { pool[t] = v; });
-    __syncthreads();
+    assemble_extend_add<KIND>(d, al, ax, pool, pil, il.len, tid, 512,
+                              [&](int t, double v) { pool[t] = v; },
+                              [&](int i, int j, double v) { front_add(&F[i + (long long) j * ld], v); },
+                              [&]() { __syncthreads(); });
     CS3_WSTAMP(1);
 
     bool bad = false;
@@ -2341,8 +2462,8 @@ k_front_il(const FrontDesc *__restrict__ fdesc, int first, const int *__restrict
 
     // ---- assembly: sum every run of equal targets in a register, store it once
     {
-        const int np = d.asm_count;                                           // multiple of 16
-        const int *pr = pairs + 2 * d.asm_begin;
+        const int np = d.a_count;                                             // multiple of 16
+        const int *pr = pairs + 2 * d.a_begin;
         int cur = -1;
         double acc = 0.0;
         for (int base = 0; base < np; base += 64) {
@@ -3299,10 +3420,9 @@ static int big_group_blocks(const LaunchGroup &g) { return (g.max_w + BIG_NB - 1
 
 static hipError_t launch_big_gather(const DeviceFactor &D, const LaunchGroup &g, hipStream_t st)
 {
-    const int chunks = (int) (g.max_asm >> 6);
-    const int gx = std::max(1, std::min(64, (chunks + 4 * GATHER_UNROLL - 1) / (4 * GATHER_UNROLL)));
-    hipLaunchKernelGGL(k_big_gather, dim3(gx, (unsigned) D.batch, g.count), dim3(256), 0, st, D.fdesc, g.first,
-                       D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool_pm, D.nnz_a, D.pm_stride, IlView{D.pool_il, D.il_len});
+    const int gx = std::max(1, std::min(64, (g.max_r + 7) / 8));           // workgroups per front: eight columns each, at most 64
+    hipLaunchKernelGGL(k_big_gather, dim3(gx, (unsigned) D.batch, g.count), dim3(256), 0, st, D.fdesc, g.first, D.kind,
+                       AsmLists{D.fa_tgt, D.fa_src, D.ch_tab, D.rel_idx}, D.ax, D.pool_pm, D.nnz_a, D.pm_stride, IlView{D.pool_il, D.il_len});
     CS3_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -3346,7 +3466,7 @@ static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g
     if (g.cls == FC_SUB) return launch_sub_factor(D, g.first, D.fwd_in_factor, inv_tol, st);     // a tier of the bottom forest
     if (big_group_in_one_workgroup(KIND, D.batch, g)) {
         hipLaunchKernelGGL((k_front_wg<KIND, WG_NB>), dim3((unsigned) g.count, batch), dim3(512), wg_lds_bytes(KIND, g), st, D.fdesc,
-                           g.first, D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool_pm, D.nnz_a, D.pm_stride,
+                           g.first, AsmLists{D.fa_tgt, D.fa_src, D.ch_tab, D.rel_idx}, D.ax, D.pool_pm, D.nnz_a, D.pm_stride,
                            IlView{D.pool_il, D.il_len}, inv_tol, D.status, wg_panel_ld(g), D.tbuf);
         CS3_LAUNCH_CHECK();
         return hipSuccess;
@@ -3367,7 +3487,7 @@ static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g
     dim3 grid((unsigned) g.count, batch);
     const size_t ld = (size_t) (g.max_r | 1);
     const size_t lds = (ld * (size_t) g.max_r + 4 * (size_t) g.max_r + 6) * sizeof(double);
-#define CS3_FRONT_ARGS D.fdesc, g.first, D.asm_src, D.asm_tgt, D.long_src, D.ax, D.pool_pm, D.nnz_a, D.pm_stride, IlView{D.pool_il, D.il_len}, inv_tol, D.status, D.tbuf
+#define CS3_FRONT_ARGS D.fdesc, g.first, AsmLists{D.fa_tgt, D.fa_src, D.ch_tab, D.rel_idx}, D.ax, D.pool_pm, D.nnz_a, D.pm_stride, IlView{D.pool_il, D.il_len}, inv_tol, D.status, D.tbuf
     switch (g.cls) {
     case FC_R16:
     case FC_R32:      // only present when the analysis split the small fronts off (batched handles)
@@ -3791,7 +3911,7 @@ static void absorb_small_group(std::vector<LaunchGroup> &out, const LaunchGroup 
         out.back().count <= promote_max() && out.back().first + out.back().count == g.first) {
         LaunchGroup &m = out.back();
         m.cls = wg_cls; m.count += g.count;
-        m.max_r = std::max(m.max_r, g.max_r); m.max_w = std::max(m.max_w, g.max_w); m.max_asm = std::max(m.max_asm, g.max_asm);
+        m.max_r = std::max(m.max_r, g.max_r); m.max_w = std::max(m.max_w, g.max_w);
         m.n16 = 0;
     } else {
         out.push_back(g);

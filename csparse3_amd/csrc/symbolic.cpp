@@ -834,16 +834,34 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
             for (i64 k = 0; k < r; ++k) where[st[k]] = -1;
         }
     }
-    S.asm_ptr.assign(ns + 1, 0);
-    S.asm_src.clear(); S.asm_tgt.clear(); S.long_src.clear();
+    // What the factor kernels read per front (the level kernels; the forest has its own copies, fill_forest):
+    //   * its entries of A as (target, entry of Ax) -- scattered into the zeroed front;
+    //   * a table of its children (update rows, row map, block offset and leading dimension) -- EXTEND-ADD: the block of
+    //     child c is added through its row map, F(rel[i], rel[j]) += C(i, j), children in order.
+    // Round 1 and 2 built one sorted (target, source) list per front instead: 8 bytes of index per 8 bytes of value, a
+    // segmented sum per 64 entries, and half of this step's time.  The lane = matrix fronts of large batches (FC_IL) keep
+    // their pair lists (ila_pairs): every lane runs the same scalar algorithm there.
+    S.fa_ptr.assign(ns + 1, 0); S.fa_tgt.clear(); S.fa_src.clear();
+    S.ch_ptr.assign(ns + 1, 0); S.ch_tab.clear();
     S.ila_ptr.assign(ns + 1, 0);
     S.ila_pairs.clear();
     {
         std::vector<Item> items, sorted;
         std::vector<i64> sort_count;
         for (i32 s = 0; s < ns; ++s) {
-            if (in_forest(s)) {                 // assembled by extend-add inside its task (fill_forest below): no gather list
-                S.asm_ptr[s + 1] = (i64) S.asm_tgt.size();
+            if (!in_forest(s) && S.sn_class[s] != FC_IL) {
+                for (i64 e = fa_ptr[s]; e < fa_ptr[s + 1]; ++e) { S.fa_tgt.push_back(fa_item[e].tgt); S.fa_src.push_back(~fa_item[e].src); }
+                for (i32 cp = S.child_ptr[s]; cp < S.child_ptr[s + 1]; ++cp) {
+                    const i32 c = S.child_idx[cp];
+                    S.ch_tab.push_back((i32) (order_r(c) - width(c)));
+                    S.ch_tab.push_back((i32) S.rel_ptr[c]);
+                    S.ch_tab.push_back((i32) S.cb_off[c]);
+                    S.ch_tab.push_back(S.cb_ld[c]);
+                }
+            }
+            S.fa_ptr[s + 1] = (i64) S.fa_tgt.size();
+            S.ch_ptr[s + 1] = (i64) (S.ch_tab.size() / 4);
+            if (in_forest(s) || S.sn_class[s] != FC_IL) {
                 S.ila_ptr[s + 1] = (i64) (S.ila_pairs.size() / 2);
                 continue;
             }
@@ -858,18 +876,17 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
                         items.push_back(Item{target_of(s, rel[ii], rel[jj]), (i32) (base + ii + jj * ldc)});
             }
             {
-                // stable counting sort by target (targets are positions inside the front's image or buffer: a range of at
-                // most r (r | 1), against half a million items at the top of a 50 000-column tree)
+                // stable counting sort by target (front-local positions)
                 const i64 r = order_r(s);
-                const i64 base = (S.sn_class[s] == FC_BIG) ? S.lpan_off[s] : 0, range = r * (r | 1) + 1;
+                const i64 range = r * (r | 1) + 1;
                 sort_count.assign((size_t) range + 1, 0);
-                for (const Item &it : items) ++sort_count[(size_t) (it.tgt - base) + 1];
+                for (const Item &it : items) ++sort_count[(size_t) it.tgt + 1];
                 for (i64 t = 0; t < range; ++t) sort_count[(size_t) t + 1] += sort_count[(size_t) t];
                 sorted.resize(items.size());
-                for (const Item &it : items) sorted[(size_t) sort_count[(size_t) (it.tgt - base)]++] = it;
+                for (const Item &it : items) sorted[(size_t) sort_count[(size_t) it.tgt]++] = it;
                 items.swap(sorted);
             }
-            if (S.sn_class[s] == FC_IL) {
+            {
                 // lane = matrix assembly: (target, source) pairs in target order in which EVERY stored entry of the
                 // front appears (an entry without a source starts at zero), so each is written exactly once
                 const i64 r = order_r(s);
@@ -883,14 +900,10 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
                     }
                 if (a != items.size()) throw std::runtime_error("analyze: source outside the stored part of a front");
                 while ((S.ila_pairs.size() / 2) % 16) { S.ila_pairs.push_back(-1); S.ila_pairs.push_back(IL_ZERO); }
-            } else {
-                emit_runs(items, S.asm_tgt, S.asm_src, S.long_src);
             }
-            S.asm_ptr[s + 1] = (i64) S.asm_tgt.size();
             S.ila_ptr[s + 1] = (i64) (S.ila_pairs.size() / 2);
         }
     }
-    if (S.asm_tgt.size() >= ((size_t) 1 << 31)) throw std::runtime_error("analyze: assembly list exceeds 32-bit offsets");
     if (ntiers > 0) fill_forest(S, fa_ptr, fa_item);
 
     tick("9. assembly lists");
@@ -909,7 +922,6 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
             const i32 f = S.sched[t];
             g.max_r = std::max<i32>(g.max_r, (i32) order_r(f));
             g.max_w = std::max<i32>(g.max_w, (i32) width(f));
-            g.max_asm = std::max<i64>(g.max_asm, S.asm_ptr[f + 1] - S.asm_ptr[f]);
             ++t;
         }
         g.count = t - g.first;
@@ -1057,8 +1069,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
 
     if (getenv("CS3_DUMP_GROUPS")) {
         for (const LaunchGroup &g : S.groups)
-            fprintf(stderr, "factor level %2d cls %d count %6d max_r %4d max_w %4d max_asm %lld\n", g.level, g.cls, g.count,
-                    g.max_r, g.max_w, (long long) g.max_asm);
+            fprintf(stderr, "factor level %2d cls %d count %6d max_r %4d max_w %4d\n", g.level, g.cls, g.count, g.max_r, g.max_w);
         for (const LaunchGroup &g : S.sgroups)
             fprintf(stderr, "solve  level %2d kind %d count %6d max_r %4d max_w %4d\n", g.level, g.cls, g.count, g.max_r, g.max_w);
         for (const LaunchGroup &g : S.sgroups1)

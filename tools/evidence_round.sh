@@ -2,7 +2,7 @@
 # All GPU-side evidence of a round in one gpurun call:  tools/evidence_round.sh r02
 # (config 3 trace + PMC passes, config 4 / 5 kernel stats, SQ counters of config 5, 2-rank gloo rehearsal, bench JSON)
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 bash tools/profile_round.sh $TAG
 bash tools/profile_cfg4.sh ${TAG}_cfg4_1024 1024

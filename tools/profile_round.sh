@@ -4,7 +4,7 @@
 # 1. kernel trace + stats of the bench command, 2. FETCH_SIZE pass, 3. WRITE_SIZE pass (PMC passes carry
 # no trace domain other than --kernel-trace, as the pool requires).  Outputs land in gpurun_out/<tag>/.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

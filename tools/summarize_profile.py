@@ -39,8 +39,9 @@ def per_kernel(kind):
 
 
 fetch, write = per_kernel("fetch"), per_kernel("write")
-factor_kernels = [n for n in fetch if n.startswith("k_front") or n.startswith("k_big")]
-solve_kernels = [n for n in fetch if n.startswith("k_fwd") or n.startswith("k_bwd") or n.startswith("k_permute")]
+factor_kernels = [n for n in fetch if n.startswith("k_front") or n.startswith("k_big") or n.startswith("k_sub_factor")]
+solve_kernels = [n for n in fetch if n.startswith("k_fwd") or n.startswith("k_bwd") or n.startswith("k_permute") or
+                 n.startswith("k_sub_fwd") or n.startswith("k_sub_bwd")]
 kb = lambda table, names: sum(table.get(n, {"kb_per_step": 0.0})["kb_per_step"] for n in names)
 # FETCH_SIZE / WRITE_SIZE are KB (x 1024).  Calibration on known byte counts in this very profile:
 #   __amd_rocclr_copyBuffer (Ax + b, 16 B/lane streaming): FETCH_SIZE reads exactly 1/2 of the bytes copied,
@@ -56,6 +57,9 @@ out = {
                     "note": "copyBuffer moves the same bytes in and out: fetch/write ratio = %.3f (guide: 0.5)"
                             % (copy_fetch / copy_write if copy_write else 0.0)},
 }
+out["prologue"] = {"fetch_size_kb": kb(fetch, ["k_prologue"]), "write_size_kb": kb(write, ["k_prologue"]),
+                   "note": "one launch before every (re)factorisation: copy of the caller's values (twice with a bottom forest: "
+                           "original order and forest order), zeros of the big-front buffers, status word; not in `factor`, as in round 2"}
 out["factor"]["hbm_bytes_corrected"] = (2 * out["factor"]["fetch_size_kb"] + out["factor"]["write_size_kb"]) * 1024
 out["solve"]["hbm_bytes_corrected"] = (2 * out["solve"]["fetch_size_kb"] + out["solve"]["write_size_kb"]) * 1024
 json.dump({"fetch": fetch, "write": write}, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)

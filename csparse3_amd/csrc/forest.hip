@@ -161,7 +161,7 @@ __device__ __forceinline__ void sub_eliminate(double (&row)[SUB_NC], double &rhs
             const double rpk = rp;
             if (k + 1 < NC) {
                 if (KIND == CS3_LU) row[k + 1] -= l * bcast_lane(row[k + 1], k);
-                else { const double lj = bcast_lane(row[k], k + 1); row[k + 1] -= (lane >= k + 1 ? l : 0.0) * lj; }
+                else { const double lj = bcast_lane(row[k], k + 1); row[k + 1] -= l * lj; }
                 piv = bcast_lane(row[k + 1], k + 1);
                 dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
                 rp = fast_rcp(dg);
@@ -180,7 +180,7 @@ __device__ __forceinline__ void sub_eliminate(double (&row)[SUB_NC], double &rhs
 #pragma unroll
                     for (int j = (j0 > k + 2 ? j0 : k + 2); j < j0 + 8; ++j) {
                         if (KIND == CS3_LU) row[j] -= l * bc[j - j0];
-                        else row[j] -= (lane >= j ? l : 0.0) * bc[j - j0];
+                        else row[j] -= l * bc[j - j0];
                     }
                 }
             }
@@ -387,7 +387,7 @@ sub_coop_front(const SubScalars &ds, int part, double *gimg, int img_stride, int
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
                 if (KIND == CS3_LU) d[j] -= l * bc[j];
-                else d[j] -= (lane >= pc0 + j ? l : 0.0) * bc[j];
+                else d[j] -= l * bc[j];
             }
             if (RHS && last) {
                 if (KIND == CS3_CHOLESKY && g < w) { const double rpg = bcast_lane(lv, g); if (lane == g) rhs *= rpg; }
@@ -449,7 +449,7 @@ sub_coop_front(const SubScalars &ds, int part, double *gimg, int img_stride, int
                 const double rpk = rp;
                 if (k + 1 < NC) {
                     const double lj = bcast_lane(d[k], pl + 1);
-                    d[k + 1] -= (lane >= pl + 1 ? l : 0.0) * lj;
+                    d[k + 1] -= l * lj;
                     piv = bcast_lane(d[k + 1], pl + 1);
                     dg = sqrt(piv);
                     rp = fast_rcp(dg);
@@ -466,7 +466,7 @@ sub_coop_front(const SubScalars &ds, int part, double *gimg, int img_stride, int
 #pragma unroll
                 for (int j = k + 2; j < NC; ++j) bc[j] = bcast_lane(d[k], pc0 + j);
 #pragma unroll
-                for (int j = k + 2; j < NC; ++j) d[j] -= (lane >= pc0 + j ? l : 0.0) * bc[j];
+                for (int j = k + 2; j < NC; ++j) d[j] -= l * bc[j];
             }
         }
     }

@@ -388,6 +388,9 @@ constexpr int PAIR_NC = 16;                   // columns per wave of a two-wave 
 // rather than behind a branch (a wave-uniform branch per pivot and column group cost the lone wave 200 cycles per pivot).
 // SKIP: steps past npiv are skipped behind one wave-uniform branch each (for a slice nobody waits for: the trailing
 // steps of a front's second half are mostly such steps).
+// (Cholesky: a column update runs in EVERY lane below the pivot row, also where the entry lies above the diagonal of the
+//  block -- those entries are never read, stored or checked, and leaving them alone cost a select or a lane mask per
+//  column update, a quarter of the instructions of a step.)
 template <int KIND, int NC, bool SKIP = false, class Publish>
 __device__ __forceinline__ void eliminate_slice(double (&d)[NC], int c0, bool keep_unscaled, Publish publish, int npiv = 1 << 30)
 {
@@ -407,7 +410,7 @@ __device__ __forceinline__ void eliminate_slice(double (&d)[NC], int c0, bool ke
         if (KIND == CS3_CHOLESKY && lane == pl && pl < npiv) d[k] = (piv > 0.0) ? dg : -1.0;
         if (k + 1 < NC) {
             if (KIND == CS3_LU) d[k + 1] -= l * bcast_lane(d[k + 1], pl);
-            else { const double lj = bcast_lane(d[k], pl + 1); if (lane >= pl + 1) d[k + 1] -= l * lj; }
+            else { const double lj = bcast_lane(d[k], pl + 1); d[k + 1] -= l * lj; }
             piv = bcast_lane(d[k + 1], pl + 1);
             dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
             rp = fast_rcp(dg);
@@ -426,7 +429,7 @@ __device__ __forceinline__ void eliminate_slice(double (&d)[NC], int c0, bool ke
                 const int j = j0 + u;
                 if (j < NC) {
                     if (KIND == CS3_LU) d[j] -= l * bc[u];
-                    else if (lane >= c0 + j) d[j] -= l * bc[u];
+                    else d[j] -= l * bc[u];
                 }
             }
         }
@@ -471,7 +474,7 @@ __device__ __forceinline__ void eliminate_pair(double (&d)[PAIR_NC], int part, b
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 if (KIND == CS3_LU) d[j0 + u] -= l * bc[u];
-                else if (lane >= NC + j0 + u) d[j0 + u] -= l * bc[u];
+                else d[j0 + u] -= l * bc[u];
             }
         }
     }
@@ -509,7 +512,7 @@ __device__ __forceinline__ void eliminate_parts(double (&d)[PAIR_NC], int part, 
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     if (KIND == CS3_LU) d[j0 + u] -= l * bc[u];
-                    else if (lane >= c0 + j0 + u) d[j0 + u] -= l * bc[u];
+                    else d[j0 + u] -= l * bc[u];
                 }
             }
         }
@@ -616,7 +619,7 @@ front_wave_body(const FrontDesc &d, int first, double *F,
                 if (KIND == CS3_CHOLESKY && lane == k) row[k] = (piv > 0.0) ? dg : -1.0;
                 if (k + 1 < NC) {
                     if (KIND == CS3_LU) row[k + 1] -= l * bcast_lane(row[k + 1], k);
-                    else { const double lj = bcast_lane(row[k], k + 1); row[k + 1] -= (lane >= k + 1 ? l : 0.0) * lj; }
+                    else { const double lj = bcast_lane(row[k], k + 1); row[k + 1] -= l * lj; }
                     piv = bcast_lane(row[k + 1], k + 1);
                     dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
                     rp = fast_rcp(dg);
@@ -633,7 +636,7 @@ front_wave_body(const FrontDesc &d, int first, double *F,
 #pragma unroll
                         for (int j = (j0 > k + 2 ? j0 : k + 2); j < j0 + 8; ++j) {
                             if (KIND == CS3_LU) row[j] -= l * bc[j - j0];
-                            else row[j] -= (lane >= j ? l : 0.0) * bc[j - j0];
+                            else row[j] -= l * bc[j - j0];
                         }
                     }
                 }
@@ -836,7 +839,7 @@ __device__ __forceinline__ void eliminate_block(double (&d)[NBK], bool keep_unsc
         if (KIND == CS3_CHOLESKY && lane == k) d[k] = (piv > 0.0) ? dg : -1.0;
         if (k + 1 < NBK) {
             if (KIND == CS3_LU) d[k + 1] -= l * bcast_lane(d[k + 1], k);
-            else { const double lj = bcast_lane(d[k], k + 1); if (lane >= k + 1) d[k + 1] -= l * lj; }
+            else { const double lj = bcast_lane(d[k], k + 1); d[k + 1] -= l * lj; }
             piv = bcast_lane(d[k + 1], k + 1);
             dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
             rp = fast_rcp(dg);
@@ -856,7 +859,7 @@ __device__ __forceinline__ void eliminate_block(double (&d)[NBK], bool keep_unsc
                 const int j = j0 + u;
                 if (j < NBK) {
                     if (KIND == CS3_LU) d[j] -= l * bc[u];
-                    else if (lane >= j) d[j] -= l * bc[u];                          // L(j, k): lane j, register k
+                    else d[j] -= l * bc[u];                                         // L(j, k): lane j, register k
                 }
             }
         }

@@ -78,5 +78,61 @@ __device__ __forceinline__ bool handover_wait(lds_int_ptr ready, int need, int *
     return true;
 }
 
+// ---- one wave eliminates a front of order <= 32: lane = row, 32 register columns (the forest's tasks and the level
+// kernels' one-wave fronts share it).  Elimination only: column k of the registers is column k of the front for the whole
+// loop (no stores, no shifting inside it); the reciprocal of the next pivot is issued right after the first column update
+// of a step, behind which its latency hides.  Pivot checks only raise `suspect` (the caller then looks for the column, a
+// rare path); RHS carries one vector column along (the fused forward sweep).
+template <int KIND, bool RHS>
+__device__ __forceinline__ void sub_eliminate(double (&row)[32], double &rhs, int r, int w, double inv_tol, bool &suspect)
+{
+    constexpr int NC = 32;
+    const int lane = threadIdx.x & 63;
+    double piv = bcast_lane(row[0], 0);
+    double dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
+    double rp = fast_rcp(dg);
+#pragma unroll
+    for (int k0 = 0; k0 < NC; k0 += 8) {
+      if (k0 < w) {                                             // (eight steps skipped at once past the last pivot)
+#pragma unroll
+       for (int k = k0; k < k0 + 8; ++k) {
+        if (k < w) {
+            const bool below = lane > k;
+            const double l = below ? row[k] * rp : 0.0;         // multiplier, zero on and above the pivot row
+            if (below) row[k] = l;
+            if (KIND == CS3_CHOLESKY && lane == k) row[k] = (piv > 0.0) ? dg : -1.0;
+            if (KIND == CS3_LU) suspect = (int) suspect | (int) !(fabs(l) <= inv_tol) | (int) !(fabs(piv) > 0.0) | (int) !(fabs(piv) < 1.0e300);
+            else suspect = (int) suspect | (int) !(piv > 0.0);
+            const double rpk = rp;
+            if (k + 1 < NC) {
+                if (KIND == CS3_LU) row[k + 1] -= l * bcast_lane(row[k + 1], k);
+                else { const double lj = bcast_lane(row[k], k + 1); row[k + 1] -= l * lj; }
+                piv = bcast_lane(row[k + 1], k + 1);
+                dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
+                rp = fast_rcp(dg);
+            }
+            if (RHS) {                                          // forward substitution: y_k final, rows below take it
+                if (KIND == CS3_CHOLESKY && lane == k) rhs *= rpk;
+                rhs -= l * bcast_lane(rhs, k);
+            }
+#pragma unroll
+            for (int j0 = (k + 2) & ~7; j0 < NC; j0 += 8) {
+                if (j0 < r) {                                   // skip register groups beyond the front
+                    double bc[8];
+#pragma unroll
+                    for (int j = (j0 > k + 2 ? j0 : k + 2); j < j0 + 8; ++j)
+                        bc[j - j0] = (KIND == CS3_LU) ? bcast_lane(row[j], k) : bcast_lane(row[k], j);
+#pragma unroll
+                    for (int j = (j0 > k + 2 ? j0 : k + 2); j < j0 + 8; ++j) {
+                        if (KIND == CS3_LU) row[j] -= l * bc[j - j0];
+                        else row[j] -= l * bc[j - j0];
+                    }
+                }
+            }
+        }
+       }
+      }
+    }
+}
 
 }  // namespace cs3

@@ -52,8 +52,6 @@ __device__ __forceinline__ double *il_lane_base(const IlView &il, long long m)
 constexpr int ASM_DUMMY_T = 0x3fffffff;
 constexpr int ASM_LONG_T = 0x40000000;
 constexpr int GATHER_UNROLL = 4;
-constexpr int GATHER_UNROLL_BIG = 16;           // k_front_wg: 130 entries per thread on a 257 x 257 root, two round trips per pass
-constexpr int GATHER_UNROLL_WG = 8;             // one workgroup of 8 waves per front (fronts of order > 64): 4096 entries per pass
 
 // Fetch(s) returns the address of source s (an unconditional load keeps loads in flight).
 template <class Fetch>
@@ -146,7 +144,7 @@ __device__ __forceinline__ void assemble_extend_add(const FrontDesc &d, const As
         put(al.fa_tgt[idx], ax[al.fa_src[idx]]);
     }
     sync();
-    const int lane = tid & 63, wv = tid >> 6, nw = nth >> 6;
+    const int lane = tid & 63;
     const int4 *tab = (const int4 *) al.ch_tab + d.ch_begin;
     for (int c = 0; c < d.ch_count; ++c) {
         const int4 ce = tab[c];
@@ -551,7 +549,6 @@ front_wave_body(const FrontDesc &d, int first, double *F,
     auto home = [&](int off) -> double * { return (off < il.len) ? pil + (long long) off * 64 : pool + off; };
     // four waves assemble the front (the gather is latency-bound: more loads in flight), one eliminates it
     CS3_STAMP(0);
-    const int nwaves = blockDim.x >> 6;
     for (int i = threadIdx.x; i < r * ld; i += blockDim.x) F[i] = 0.0;
     if (threadIdx.x == 0 && blockDim.x > 64) *(int *) (F + r * ld + 2) = 0;                     // eliminate_parts' counter
     __syncthreads();
@@ -593,94 +590,88 @@ front_wave_body(const FrontDesc &d, int first, double *F,
             }
         }
     } else if (threadIdx.x < 64) {
-    double row[NC];
-    {
-        const int li = lane < r ? lane : 0;             // unconditional LDS reads, then select
+        // one wave, lane = row.  No masks on the reads: lanes >= r copy row 0 and columns >= r the last column -- what
+        // they compute goes nowhere (a select on the scalar r turns every one of these reads into a branch with a wait)
+        static_assert(NC == 32, "sub_eliminate holds 32 register columns");
+        double row[NC], unused = 0.0;
+        {
+            const int li = lane < r ? lane : 0;
 #pragma unroll
-        for (int j = 0; j < NC; ++j) {
-            const double v = F[li + (j < r ? j : 0) * ld];
-            row[j] = (lane < r && j < r) ? v : 0.0;
-        }
-    }
-    CS3_STAMP(3);
-    // Elimination only: column k of the registers is column k of the front for the whole loop (no
-    // stores, no checks, no shifting inside it); the reciprocal of the next pivot is issued right
-    // after the first column update of a step, behind which its latency hides.
-    {
-        double piv = bcast_lane(row[0], 0);
-        double dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
-        double rp = fast_rcp(dg);
+            for (int j0 = 0; j0 < NC; j0 += 8)
+                if (j0 < r) {                                   // (register groups beyond the front are never used)
 #pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            if (k < w) {                                        // wave-uniform
-                const bool below = lane > k;
-                const double l = below ? row[k] * rp : 0.0;     // multiplier, zero on and above the pivot row
-                if (below) row[k] = l;
-                if (KIND == CS3_CHOLESKY && lane == k) row[k] = (piv > 0.0) ? dg : -1.0;
-                if (k + 1 < NC) {
-                    if (KIND == CS3_LU) row[k + 1] -= l * bcast_lane(row[k + 1], k);
-                    else { const double lj = bcast_lane(row[k], k + 1); row[k + 1] -= l * lj; }
-                    piv = bcast_lane(row[k + 1], k + 1);
-                    dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
-                    rp = fast_rcp(dg);
+                    for (int j = j0; j < j0 + 8; ++j) row[j] = F[li + min(j, r - 1) * ld];
                 }
+        }
+        CS3_STAMP(3);
+        bool suspect = false;
+        sub_eliminate<KIND, false>(row, unused, r, w, inv_tol, suspect);
+        CS3_STAMP(4);
+        // stores: one lane-dependent region per destination, groups of eight register columns behind one wave-uniform
+        // branch each.  Pool offsets fit 32 bits (analysis refuses larger pools); a panel below il.len lives in the
+        // matrix-interleaved region (entry `off` of this matrix is pil[off * 64]).
+        const bool is_u = lane < w;
+        if (live) {
+            const int mul = d.lpan < il.len ? 64 : 1;
+            double *Lp = home((int) d.lpan) + lane * mul;
+            const int sj = r * mul;
 #pragma unroll
-                for (int j0 = (k + 2) & ~7; j0 < NC; j0 += 8) {
-                    if (j0 < r) {                               // skip register groups beyond the front
-                        // the group's broadcasts first, then its FMAs: a lane-to-scalar read needs wait states before
-                        // the vector instruction that consumes it, which the next broadcasts fill
-                        double bc[8];
+            for (int j0 = 0; j0 < NC; j0 += 8)
+                if (j0 < w) {
 #pragma unroll
-                        for (int j = (j0 > k + 2 ? j0 : k + 2); j < j0 + 8; ++j)
-                            bc[j - j0] = (KIND == CS3_LU) ? bcast_lane(row[j], k) : bcast_lane(row[k], j);
-#pragma unroll
-                        for (int j = (j0 > k + 2 ? j0 : k + 2); j < j0 + 8; ++j) {
-                            if (KIND == CS3_LU) row[j] -= l * bc[j - j0];
-                            else row[j] -= l * bc[j - j0];
+                    for (int j = j0; j < j0 + 8; ++j)
+                        if (j < w) {
+                            if (KIND == CS3_LU) Lp[j * sj] = row[j];
+                            else if (lane >= j) Lp[j * sj] = row[j];
                         }
+                }
+        }
+        if (KIND == CS3_LU && is_u) {
+            const int mul = d.upan < il.len ? 64 : 1;
+            double *Up = home((int) d.upan) + lane * d.u_sk * mul;
+            const int sj = d.u_sj * mul;
+#pragma unroll
+            for (int j0 = 0; j0 < NC; j0 += 8)
+                if (j0 + 8 > w && j0 < r) {
+#pragma unroll
+                    for (int j = j0; j < j0 + 8; ++j)
+                        if (j >= w && j < r) Up[(j - w) * sj] = row[j];
+                }
+        }
+        if (live && !is_u && has_parent) {
+            const int mul = d.cb < il.len ? 64 : 1;
+            double *cbg = home((int) d.cb) + (lane - w) * mul;
+            const int sj = nb * mul;
+#pragma unroll
+            for (int j0 = 0; j0 < NC; j0 += 8)
+                if (j0 + 8 > w && j0 < r) {
+#pragma unroll
+                    for (int j = j0; j < j0 + 8; ++j)
+                        if (j >= w && j < r) {
+                            if (KIND == CS3_LU) cbg[(j - w) * sj] = row[j];
+                            else if (lane >= j) cbg[(j - w) * sj] = row[j];
+                        }
+                }
+        }
+        if (__any(suspect & live)) {                            // rare: find the first rejected column
+            asm volatile("; rejected pivot: look for its column" ::: "memory");     // (keeps the search behind the branch)
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                if (j < w) {
+                    const double v = row[j];
+                    const double av = fabs(v);
+                    bool rej;
+                    if (KIND == CS3_LU) {
+                        const double lim = (lane == j) ? 1.0e300 : inv_tol;
+                        rej = (live & (lane >= j) & !(av <= lim)) | ((lane == j) & !(av > 0.0));
+                    } else {
+                        rej = (lane == j) & !(v > 0.0);
                     }
+                    bad_col = (rej & !bad) ? j : bad_col;
+                    bad = bad | rej;
                 }
             }
         }
-    }
-    CS3_STAMP(4);
-    if (!coop) {
-    // checks and stores, one pass.  Pool offsets fit 32 bits (analysis refuses larger pools): column j of
-    // my row goes to the L panel (j < w), else to the U panel (my row is a pivot row) or the contribution block.
-    {
-        const int lp = (int) d.lpan + lane;
-        const int base2 = (lane < w) ? (int) d.upan + lane * d.u_sk - w * d.u_sj : (int) d.cb + (lane - w) - w * nb;
-        const int stride2 = (lane < w) ? d.u_sj : nb;
-        const bool ok2 = live & ((lane < w) ? (KIND == CS3_LU) : has_parent);
-#pragma unroll
-        for (int j = 0; j < NC; ++j) {
-            if (j < r) {                                        // wave-uniform
-                const double v = row[j];
-                const double av = fabs(v);
-                const bool tri = (KIND == CS3_LU) | (lane >= j);    // Cholesky keeps the lower triangle only
-                const bool in_l = j < w;                            // wave-uniform
-                // mask logic, no short-circuit branches: multipliers |l| <= 1/tol, pivot non-zero and finite
-                bool rej;
-                if (KIND == CS3_LU) {
-                    const double lim = (lane == j) ? 1.0e300 : inv_tol;
-                    rej = (live & (lane >= j) & !(av <= lim)) | ((lane == j) & !(av > 0.0));
-                } else {
-                    rej = (lane == j) & !(v > 0.0);
-                }
-                rej = rej & in_l;
-                bad_col = (rej & !bad) ? j : bad_col;
-                bad = bad | rej;
-                const int off = in_l ? lp + j * r : base2 + j * stride2;
-                const bool ok = (in_l ? live : ok2) & tri;
-                if (ok) *home(off) = v;
-            }
-        }
-    }
-    } else if (live) {                          // my row back into the image, column by column (conflict-free)
-#pragma unroll
-        for (int j = 0; j < NC; ++j)
-            if (j < r) F[lane + j * ld] = row[j];
-    }
     }                                           // (wave 0)
     if (coop) {
         // checks and stores by all four waves from the image: a quarter of the store instructions per wave

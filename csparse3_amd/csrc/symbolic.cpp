@@ -748,13 +748,6 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
 
     tick("8. levels");
     // ---- 9. assembly lists: every entry of a front is the sum of its sources
-    auto find_row = [&](i32 s, i32 row) -> i64 {
-        const i32 *st = S.st_idx.data() + S.st_ptr[s];
-        const i64 r = order_r(s);
-        const i32 *it = std::lower_bound(st, st + r, row);
-        if (it == st + r || *it != row) throw std::runtime_error("analyze: entry outside the symbolic structure");
-        return it - st;
-    };
     // target index of front entry (ti, tj): LDS image index for resident fronts
     // (leading dimension r | 1), absolute pool offset inside the r x r buffer for big ones
     auto target_of = [&](i32 s, i64 ti, i64 tj) -> i32 {

@@ -382,8 +382,8 @@ sub_coop_front(const SubScalars &ds, int part, double *gimg, int img_stride, int
             }
         } else {
             double piv = bcast_lane(d[0], pc0);
-            double dg = sqrt(piv);
-            double rp = fast_rcp(dg);
+            double dg, rp;
+            sqrt_and_rsqrt(piv, dg, rp);
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
                 const int pl = pc0 + k;                         // the pivot's lane
@@ -393,13 +393,12 @@ sub_coop_front(const SubScalars &ds, int part, double *gimg, int img_stride, int
                 if (below) d[k] = l;
                 if (lane == pl) d[k] = (piv > 0.0) ? dg : -1.0;
                 suspect = suspect | !(piv > 0.0);
-                const double rpk = rp;
+                const double rpk = RHS ? fast_rcp(dg) : rp;     // (what the separate forward sweep multiplies by, bit for bit)
                 if (k + 1 < NC) {
                     const double lj = bcast_lane(d[k], pl + 1);
                     d[k + 1] -= l * lj;
                     piv = bcast_lane(d[k + 1], pl + 1);
-                    dg = sqrt(piv);
-                    rp = fast_rcp(dg);
+                    sqrt_and_rsqrt(piv, dg, rp);
                 }
                 if (!last) {
                     lm[k * 64 + lane] = (lane == pl) ? rpk : l;

@@ -310,8 +310,8 @@ front_lds_body(const FrontDesc &d, int first, double *F,
         }
         __syncthreads();
         const double piv = urow[k];
-        const double dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
-        const double rdg = fast_rcp(dg);           // one reciprocal per pivot: multipliers are x * (1 / pivot)
+        double dg, rdg;                            // one reciprocal per pivot: multipliers are x * (1 / pivot)
+        pivot_scale<KIND>(piv, dg, rdg);
         if (ty == tyk) {                           // 2. column k / pivot -> lcol
 #pragma unroll
             for (int b = 0; b < RJ; ++b)
@@ -396,8 +396,8 @@ __device__ __forceinline__ void eliminate_slice(double (&d)[NC], int c0, bool ke
     const int lane = threadIdx.x & 63;
     const bool stacked = lane >= 32;
     double piv = bcast_lane(d[0], c0);
-    double dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
-    double rp = fast_rcp(dg);
+    double dg, rp;
+    pivot_scale<KIND>(piv, dg, rp);
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
         const int pl = c0 + k;                                  // the pivot's lane
@@ -410,8 +410,7 @@ __device__ __forceinline__ void eliminate_slice(double (&d)[NC], int c0, bool ke
             if (KIND == CS3_LU) d[k + 1] -= l * bcast_lane(d[k + 1], pl);
             else { const double lj = bcast_lane(d[k], pl + 1); d[k + 1] -= l * lj; }
             piv = bcast_lane(d[k + 1], pl + 1);
-            dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
-            rp = fast_rcp(dg);
+            pivot_scale<KIND>(piv, dg, rp);
         }
         publish(k, l);
 #pragma unroll
@@ -479,52 +478,6 @@ __device__ __forceinline__ void eliminate_pair(double (&d)[PAIR_NC], int part, b
     eliminate_slice<KIND, NC, true>(d, NC, keep_unscaled, [](int, double) {}, npiv);
 }
 
-// The same hand-over for a front of order <= 64 split over up to four waves: wave `part` holds columns
-// [16 part, 16 part + 16) of all 64 rows (lane = row).  It applies the multipliers of the pivots to its left as they
-// appear (lm[g][lane], *ready = pivots published so far: pivots are published strictly in order, so one counter serves
-// all producers), then eliminates its own pivots and publishes them.  Only pivots < npiv exist; wave 0 publishes all 16
-// of its steps (zeros past npiv) so that it runs without a branch, the others publish the real ones only.
-template <int KIND>
-__device__ __forceinline__ void eliminate_parts(double (&d)[PAIR_NC], int part, int nparts, double *lm_generic, int *ready_generic, int npiv, int *status)
-{
-    constexpr int NC = PAIR_NC;
-    const int lane = threadIdx.x & 63;
-    auto lm = (lds_vdouble_ptr) lm_generic;
-    auto ready = (lds_int_ptr) ready_generic;
-    const bool withhold = g_withhold_handover != 0;
-    bool alive = true;
-    const int c0 = NC * part;
-    // blocks of 16 pivots to my left, whole blocks only (one branch per block, none per pivot: a block that holds a real
-    // pivot was published in full, with zero multipliers past npiv)
-    for (int g0 = 0; g0 < c0 && g0 < npiv; g0 += NC) {
-#pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            const int g = g0 + k;
-            if (alive) alive = handover_wait(ready, g, status, withhold);
-            const double l = lm[g * 64 + lane];                 // zero on and above the pivot row
-#pragma unroll
-            for (int j0 = 0; j0 < NC; j0 += 8) {
-                double bc[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) bc[u] = (KIND == CS3_LU) ? bcast_lane(d[j0 + u], g) : bcast_lane(l, c0 + j0 + u);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (KIND == CS3_LU) d[j0 + u] -= l * bc[u];
-                    else d[j0 + u] -= l * bc[u];
-                }
-            }
-        }
-    }
-    if (c0 >= npiv) return;                                     // no pivot of mine exists
-    auto publish = [&](int k, double l) {
-        lm[(c0 + k) * 64 + lane] = l;
-        if (lane == 0) handover_publish(ready, c0 + k + 1, withhold);
-    };
-    // a wave with consumers to its right runs all 16 steps without a branch; the last one skips the steps past npiv
-    if (part + 1 < nparts) eliminate_slice<KIND, NC, false>(d, c0, false, publish, npiv);
-    else eliminate_slice<KIND, NC, true>(d, c0, false, [](int, double) {}, npiv);
-}
-
 // ---------------------------------------------- front owned by ONE wave ----
 // Fronts of order r <= NC <= 64: lane i keeps ROW i of the front in NC registers, so a pivot
 // needs no barrier and no LDS: the pivot row is read lane-to-scalar (v_readlane) and each lane
@@ -550,7 +503,6 @@ front_wave_body(const FrontDesc &d, int first, double *F,
     // four waves assemble the front (the gather is latency-bound: more loads in flight), one eliminates it
     CS3_STAMP(0);
     for (int i = threadIdx.x; i < r * ld; i += blockDim.x) F[i] = 0.0;
-    if (threadIdx.x == 0 && blockDim.x > 64) *(int *) (F + r * ld + 2) = 0;                     // eliminate_parts' counter
     __syncthreads();
     CS3_STAMP(1);
     assemble_extend_add<KIND>(d, al, ax, pool, pil, il.len, (int) threadIdx.x, (int) blockDim.x,
@@ -558,143 +510,121 @@ front_wave_body(const FrontDesc &d, int first, double *F,
                               [&](int i, int j, double v) { front_add(&F[i + j * ld], v); },
                               [&]() { __syncthreads(); });
     CS3_STAMP(2);
-    const bool coop = blockDim.x > 64;          // helper waves stay for the store pass
-    if (threadIdx.x >= 64 && !coop) return;
     const int lane = threadIdx.x & 63;
     bool bad = false;
     int bad_col = 0;
     const bool has_parent = d.parent >= 0;
     const bool live = lane < r;
-    if (coop) {
-        // four-wave workgroup, front of order <= 64: wave `part` takes columns [16 part, 16 part + 16) of all rows
-        // (eliminate_parts: a lone wave is bound by the issue of two v_readlane and one FMA per column update, 470 cycles
-        // per pivot; the 16 x 16 thread grid that used to serve the orders 33..64 paid two block barriers per pivot)
-        const int part = threadIdx.x >> 6;
-        if (PAIR_NC * part < r) {
-            int *ready = (int *) (F + r * ld + 2);              // pivots handed over so far, then [pivots][64] multipliers
-            double *lm = F + r * ld + 4;
-            double hrow[PAIR_NC];
-            const int li = lane < r ? lane : 0, c0 = PAIR_NC * part;
-#pragma unroll
-            for (int j = 0; j < PAIR_NC; ++j) {
-                const double v = F[li + (c0 + j < r ? c0 + j : 0) * ld];
-                hrow[j] = (lane < r && c0 + j < r) ? v : 0.0;
-            }
-            CS3_STAMP(3);
-            eliminate_parts<KIND>(hrow, part, (r + PAIR_NC - 1) / PAIR_NC, lm, ready, w, status);
-            CS3_STAMP(4);
-            if (live) {
-#pragma unroll
-                for (int j = 0; j < PAIR_NC; ++j)
-                    if (c0 + j < r) F[lane + (c0 + j) * ld] = hrow[j];
-            }
-        }
-    } else if (threadIdx.x < 64) {
-        // one wave, lane = row.  No masks on the reads: lanes >= r copy row 0 and columns >= r the last column -- what
-        // they compute goes nowhere (a select on the scalar r turns every one of these reads into a branch with a wait)
+    {
+        // PANEL + SCHUR COMPLEMENT (at most 32 pivots).  Wave 0, lane = row, takes the w pivot columns into registers
+        // and eliminates inside them (LU: also the pivot rows, transposed: lane = column); the factored panels go back
+        // into the image, and the trailing matrix is formed from them by MFMA (schur_tiles) by all the waves there
+        // are, straight into the parent's contribution block.  Until round 3 the one wave carried all r columns
+        // through every pivot step: two lane reads and an FMA per column and pivot, 490 cycles per 1024 FMAs
+        // against the matrix pipe's 64.
         static_assert(NC == 32, "sub_eliminate holds 32 register columns");
-        double row[NC], unused = 0.0;
-        {
-            const int li = lane < r ? lane : 0;
-#pragma unroll
-            for (int j0 = 0; j0 < NC; j0 += 8)
-                if (j0 < r) {                                   // (register groups beyond the front are never used)
-#pragma unroll
-                    for (int j = j0; j < j0 + 8; ++j) row[j] = F[li + min(j, r - 1) * ld];
-                }
-        }
-        CS3_STAMP(3);
+        const int wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+        double row[NC], ut[NC], unused = 0.0;
         bool suspect = false;
-        sub_eliminate<KIND, false>(row, unused, r, w, inv_tol, suspect);
-        CS3_STAMP(4);
-        // stores: one lane-dependent region per destination, groups of eight register columns behind one wave-uniform
-        // branch each.  Pool offsets fit 32 bits (analysis refuses larger pools); a panel below il.len lives in the
-        // matrix-interleaved region (entry `off` of this matrix is pil[off * 64]).
-        const bool is_u = lane < w;
-        if (live) {
-            const int mul = d.lpan < il.len ? 64 : 1;
-            double *Lp = home((int) d.lpan) + lane * mul;
-            const int sj = r * mul;
+        const bool is_ucol = (KIND == CS3_LU) && w + lane < r;          // (wave 0) my column of the pivot rows
+        if (wave == 0) {
+            // no masks on the reads: lanes / registers past the front copy its last row / column -- what they compute
+            // goes nowhere (a select on a scalar turns every one of these reads into a branch with a wait of its own)
+            const int li = min(lane, r - 1), cj = min(w + lane, r - 1);
 #pragma unroll
             for (int j0 = 0; j0 < NC; j0 += 8)
                 if (j0 < w) {
 #pragma unroll
-                    for (int j = j0; j < j0 + 8; ++j)
-                        if (j < w) {
-                            if (KIND == CS3_LU) Lp[j * sj] = row[j];
-                            else if (lane >= j) Lp[j * sj] = row[j];
-                        }
-                }
-        }
-        if (KIND == CS3_LU && is_u) {
-            const int mul = d.upan < il.len ? 64 : 1;
-            double *Up = home((int) d.upan) + lane * d.u_sk * mul;
-            const int sj = d.u_sj * mul;
-#pragma unroll
-            for (int j0 = 0; j0 < NC; j0 += 8)
-                if (j0 + 8 > w && j0 < r) {
-#pragma unroll
-                    for (int j = j0; j < j0 + 8; ++j)
-                        if (j >= w && j < r) Up[(j - w) * sj] = row[j];
-                }
-        }
-        if (live && !is_u && has_parent) {
-            const int mul = d.cb < il.len ? 64 : 1;
-            double *cbg = home((int) d.cb) + (lane - w) * mul;
-            const int sj = nb * mul;
-#pragma unroll
-            for (int j0 = 0; j0 < NC; j0 += 8)
-                if (j0 + 8 > w && j0 < r) {
-#pragma unroll
-                    for (int j = j0; j < j0 + 8; ++j)
-                        if (j >= w && j < r) {
-                            if (KIND == CS3_LU) cbg[(j - w) * sj] = row[j];
-                            else if (lane >= j) cbg[(j - w) * sj] = row[j];
-                        }
-                }
-        }
-        if (__any(suspect & live)) {                            // rare: find the first rejected column
-            asm volatile("; rejected pivot: look for its column" ::: "memory");     // (keeps the search behind the branch)
-#pragma unroll
-            for (int j = 0; j < NC; ++j) {
-                if (j < w) {
-                    const double v = row[j];
-                    const double av = fabs(v);
-                    bool rej;
+                    for (int j = j0; j < j0 + 8; ++j) row[j] = F[li + min(j, w - 1) * ld];
                     if (KIND == CS3_LU) {
-                        const double lim = (lane == j) ? 1.0e300 : inv_tol;
-                        rej = (live & (lane >= j) & !(av <= lim)) | ((lane == j) & !(av > 0.0));
-                    } else {
-                        rej = (lane == j) & !(v > 0.0);
+#pragma unroll
+                        for (int j = j0; j < j0 + 8; ++j) ut[j] = F[min(j, w - 1) + cj * ld];
                     }
-                    bad_col = (rej & !bad) ? j : bad_col;
-                    bad = bad | rej;
+                }
+            CS3_STAMP(3);
+            sub_eliminate<KIND, false, KIND == CS3_LU>(row, unused, w, w, inv_tol, suspect, ut);
+            // what the tiles read goes back into the image: L21 and U12
+            if (has_parent) {
+                if (live && lane >= w) {
+#pragma unroll
+                    for (int j0 = 0; j0 < NC; j0 += 8)
+                        if (j0 < w) {
+#pragma unroll
+                            for (int j = j0; j < j0 + 8; ++j)
+                                if (j < w) F[lane + j * ld] = row[j];
+                        }
+                }
+                if (is_ucol) {
+#pragma unroll
+                    for (int j0 = 0; j0 < NC; j0 += 8)
+                        if (j0 < w) {
+#pragma unroll
+                            for (int j = j0; j < j0 + 8; ++j)
+                                if (j < w) F[j + (w + lane) * ld] = ut[j];
+                        }
                 }
             }
         }
-    }                                           // (wave 0)
-    if (coop) {
-        // checks and stores by all four waves from the image: a quarter of the store instructions per wave
-        __syncthreads();
-        const int nth = blockDim.x;
-        for (int e = threadIdx.x; e < r * r; e += nth) {
-            const int i = e % r, j = e / r;
-            const double v = F[i + j * ld], av = fabs(v);
-            const bool tri = (KIND == CS3_LU) | (i >= j);
-            if (j < w) {
-                bool rej;
-                if (KIND == CS3_LU) {
-                    const double lim = (i == j) ? 1.0e300 : inv_tol;
-                    rej = ((i >= j) & !(av <= lim)) | ((i == j) & !(av > 0.0));
-                } else {
-                    rej = (i == j) & !(v > 0.0);
+        if (blockDim.x > 64) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+        CS3_STAMP(4);
+        // Pool offsets fit 32 bits (analysis refuses larger pools); a panel below il.len lives in the matrix-interleaved
+        // region (entry `off` of this matrix is pil[off * 64]).
+        if (has_parent && nb > 0) {
+            const int mul = d.cb < il.len ? 64 : 1;
+            double *cbg = home((int) d.cb);
+            const int sj = nb * mul;
+            schur_tiles<KIND>(F, ld, r, w, nwv - 1 - wave, nwv, [&](int i, int c, double v) {
+                if (KIND == CS3_LU || i >= c) cbg[(i - w) * mul + (c - w) * sj] = v;
+            });
+        }
+        if (wave == 0) {
+            // the panels: one lane-dependent region per destination, groups of eight register columns behind one
+            // wave-uniform branch each
+            if (live) {
+                const int mul = d.lpan < il.len ? 64 : 1;
+                double *Lp = home((int) d.lpan) + lane * mul;
+                const int sj = r * mul;
+#pragma unroll
+                for (int j0 = 0; j0 < NC; j0 += 8)
+                    if (j0 < w) {
+#pragma unroll
+                        for (int j = j0; j < j0 + 8; ++j)
+                            if (j < w) {
+                                if (KIND == CS3_LU) Lp[j * sj] = row[j];
+                                else if (lane >= j) Lp[j * sj] = row[j];
+                            }
+                    }
+            }
+            if (is_ucol) {
+                const int mul = d.upan < il.len ? 64 : 1;
+                double *Up = home((int) d.upan) + lane * d.u_sj * mul;
+                const int sk = d.u_sk * mul;
+#pragma unroll
+                for (int j0 = 0; j0 < NC; j0 += 8)
+                    if (j0 < w) {
+#pragma unroll
+                        for (int j = j0; j < j0 + 8; ++j)
+                            if (j < w) Up[j * sk] = ut[j];
+                    }
+            }
+            if (__any(suspect & live)) {                        // rare: find the first rejected column
+                asm volatile("; rejected pivot: look for its column" ::: "memory");     // (keeps the search behind the branch)
+#pragma unroll
+                for (int j = 0; j < NC; ++j) {
+                    if (j < w) {
+                        const double v = row[j];
+                        const double av = fabs(v);
+                        bool rej;
+                        if (KIND == CS3_LU) {
+                            const double lim = (lane == j) ? 1.0e300 : inv_tol;
+                            rej = (live & (lane >= j) & !(av <= lim)) | ((lane == j) & !(av > 0.0));
+                        } else {
+                            rej = (lane == j) & !(v > 0.0);
+                        }
+                        bad_col = (rej & !bad) ? j : bad_col;
+                        bad = bad | rej;
+                    }
                 }
-                if (rej && (!bad || j < bad_col)) { bad = true; bad_col = j; }
-                if (tri) *home((int) d.lpan + i + j * r) = v;
-            } else if (i < w) {
-                if (KIND == CS3_LU) *home((int) d.upan + i * d.u_sk + (j - w) * d.u_sj) = v;
-            } else if (has_parent && tri) {
-                pool[(int) d.cb + (i - w) + (j - w) * nb] = v;
             }
         }
     }
@@ -731,7 +661,7 @@ k_front_mix(const FrontDesc *__restrict__ fdesc, int first,
     extern __shared__ __attribute__((aligned(16))) double F[];
     const long long t_start = tbuf ? (long long) __builtin_amdgcn_s_memtime() : 0;
     const FrontDesc d = fdesc[first + blockIdx.x];
-    if (d.r <= 32)                      // (four waves gather, two share the elimination)
+    if (d.w <= 32)                      // (four waves assemble, one factors the panel, four form the Schur complement)
         front_wave_body<KIND, 32>(d, first, F, al, ax_all, pool_all, nnz_a, pool_stride, il,
                                   inv_tol, status, tbuf, t_start);
     else
@@ -820,8 +750,8 @@ __device__ __forceinline__ void eliminate_block(double (&d)[NBK], bool keep_unsc
     const int lane = threadIdx.x & 63;
     const bool stacked = lane >= 32;
     double piv = bcast_lane(d[0], 0);
-    double dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
-    double rp = fast_rcp(dg);
+    double dg, rp;
+    pivot_scale<KIND>(piv, dg, rp);
 #pragma unroll
     for (int k = 0; k < NBK; ++k) {
         const bool below = lane > k;
@@ -832,8 +762,7 @@ __device__ __forceinline__ void eliminate_block(double (&d)[NBK], bool keep_unsc
             if (KIND == CS3_LU) d[k + 1] -= l * bcast_lane(d[k + 1], k);
             else { const double lj = bcast_lane(d[k], k + 1); d[k + 1] -= l * lj; }
             piv = bcast_lane(d[k + 1], k + 1);
-            dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
-            rp = fast_rcp(dg);
+            pivot_scale<KIND>(piv, dg, rp);
         }
         // the broadcasts of EB columns go out before their FMAs: a lane-to-scalar read needs wait states before the
         // vector instruction that consumes it, which the next broadcasts fill
@@ -2508,9 +2437,9 @@ k_front_il(const FrontDesc *__restrict__ fdesc, int first, const int *__restrict
 #pragma unroll
         for (int kk = 0; kk < IL_KB; ++kk) {
             const double piv = dd[kk][kk];
-            const double dg = (KIND == CS3_CHOLESKY) ? sqrt(piv) : piv;
+            double dg;
+            pivot_scale<KIND>(piv, dg, rd[kk]);
             bool rej = (KIND == CS3_LU) ? (!(fabs(piv) > 0.0) || !(fabs(piv) < 1.0e300)) : !(piv > 0.0);
-            rd[kk] = fast_rcp(dg);
             if (KIND == CS3_CHOLESKY) dd[kk][kk] = (piv > 0.0) ? dg : -1.0;
 #pragma unroll
             for (int ii = kk + 1; ii < IL_KB; ++ii) {
@@ -3486,13 +3415,8 @@ static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g
     case FC_R16:
     case FC_R32:      // only present when the analysis split the small fronts off (batched handles)
         hipLaunchKernelGGL((k_front_wave<KIND>), grid, dim3(64), lds, st, CS3_FRONT_ARGS); break;
-    case FC_R64: {    // (+ the counter and the multipliers of the shared elimination behind the image: [pivots][64])
-        // orders 33..64 run on the 16 x 16 thread grid (front_lds_body): through the shared elimination (four waves x 16
-        // columns) they were equal on config 3 and slower on batches (3.99 against 3.57 ms on 512 matrices: waves that
-        // wait for multipliers take issue slots from the other fronts of a full CU)
-        const size_t lm = (size_t) 64 * ((std::min(g.max_w, 64) + PAIR_NC - 1) / PAIR_NC * PAIR_NC) + 4;
-        hipLaunchKernelGGL((k_front_mix<KIND>), grid, dim3(256), lds + lm * sizeof(double), st, CS3_FRONT_ARGS); break;
-    }
+    case FC_R64:      // at most 32 pivots: panel by one wave + Schur complement by MFMA; more: the 16 x 16 thread grid
+        hipLaunchKernelGGL((k_front_mix<KIND>), grid, dim3(256), lds, st, CS3_FRONT_ARGS); break;
     default:
         // 16 pivots per block step: the one-wave elimination of a block costs NBK^2 column updates, the MFMA update that
         // follows is cheap, so narrow blocks win (measured: 32 -> 16 took 4 % off the batched config, neutral on config 3;

@@ -188,6 +188,46 @@ __device__ __forceinline__ void sub_eliminate(double (&row)[32], double &rhs, in
     sub_eliminate<KIND, RHS, false>(row, rhs, r, w, inv_tol, suspect, none);
 }
 
+// The pivot ROWS of an LU front by themselves, transposed: lane = a column of the front (all r of them, the pivot columns
+// included), ut[i] = F(i, column) for the w pivot rows.  Row k is final when its turn comes; the rows below take
+// ut[i] -= (F(i, k) / pivot) ut[k] with the multiplier formed from lane k of ut[i] -- a wave-uniform value, so this wave needs
+// nothing from the wave that factors the pivot COLUMNS (sub_eliminate), and the two run side by side.  Every entry sees
+// the same operations in the same order as in the one-wave panel form: U11 comes out identical in both waves (only the
+// columns to the right of the block, U12, are taken from here).
+__device__ __forceinline__ void rows_eliminate_lu(double (&ut)[32], int w)
+{
+    constexpr int NC = 32;
+    double piv = bcast_lane(ut[0], 0);
+    double rp = fast_rcp(piv);
+#pragma unroll
+    for (int k0 = 0; k0 < NC; k0 += 8) {
+      if (k0 < w) {
+#pragma unroll
+       for (int k = k0; k < k0 + 8; ++k) {
+        if (k < w) {
+            const double rpk = rp;
+            if (k + 1 < NC) {
+                const double l1 = bcast_lane(ut[k + 1], k) * rpk;
+                ut[k + 1] -= l1 * ut[k];
+                piv = bcast_lane(ut[k + 1], k + 1);
+                rp = fast_rcp(piv);
+            }
+#pragma unroll
+            for (int i0 = (k + 2) & ~7; i0 < NC; i0 += 8) {
+                if (i0 < w) {
+                    double li[8];
+#pragma unroll
+                    for (int i = (i0 > k + 2 ? i0 : k + 2); i < i0 + 8; ++i) li[i - i0] = bcast_lane(ut[i], k) * rpk;
+#pragma unroll
+                    for (int i = (i0 > k + 2 ? i0 : k + 2); i < i0 + 8; ++i) ut[i] -= li[i - i0] * ut[k];
+                }
+            }
+        }
+       }
+      }
+    }
+}
+
 // ---- the trailing matrix of a front whose image lives in LDS (column-major, leading dimension ld), by
 // v_mfma_f64_16x16x4:   C(i, j) - sum_{k < w} L(i, k) U(k, j)   for i, j in [w, r), in 16 x 16 tiles dealt to `nwaves`
 // waves; every entry of the result is handed to out(i, j, value) exactly once (Cholesky: the tiles on and below the

@@ -523,47 +523,58 @@ front_wave_body(const FrontDesc &d, int first, double *F,
         // through every pivot step: two lane reads and an FMA per column and pivot, 490 cycles per 1024 FMAs
         // against the matrix pipe's 64.
         static_assert(NC == 32, "sub_eliminate holds 32 register columns");
-        const int wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+        const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6), nwv = blockDim.x >> 6;
         double row[NC], ut[NC], unused = 0.0;
         bool suspect = false;
-        const bool is_ucol = (KIND == CS3_LU) && w + lane < r;          // (wave 0) my column of the pivot rows
+        // LU with waves to spare: the pivot rows are wave 1's, on its own (rows_eliminate_lu), while wave 0 factors
+        // the pivot columns -- in one wave the two halves queue behind each other, 2 (w - k) column updates per pivot
+        const bool split = (KIND == CS3_LU) && nwv > 1;
+        const int uwave = split ? 1 : 0;
+        const int ucol = split ? lane : w + lane;                       // (wave `uwave`) my column of the pivot rows
+        const bool is_ucol = (KIND == CS3_LU) && ucol >= w && ucol < r;
+        // no masks on the reads: lanes / registers past the front copy its last row / column -- what they compute
+        // goes nowhere (a select on a scalar turns every one of these reads into a branch with a wait of its own)
+        if (KIND == CS3_LU && wave == uwave) {
+            const int cj = min(ucol, r - 1);
+#pragma unroll
+            for (int j0 = 0; j0 < NC; j0 += 8)
+                if (j0 < w) {
+#pragma unroll
+                    for (int j = j0; j < j0 + 8; ++j) ut[j] = F[min(j, w - 1) + cj * ld];
+                }
+        }
         if (wave == 0) {
-            // no masks on the reads: lanes / registers past the front copy its last row / column -- what they compute
-            // goes nowhere (a select on a scalar turns every one of these reads into a branch with a wait of its own)
-            const int li = min(lane, r - 1), cj = min(w + lane, r - 1);
+            const int li = min(lane, r - 1);
 #pragma unroll
             for (int j0 = 0; j0 < NC; j0 += 8)
                 if (j0 < w) {
 #pragma unroll
                     for (int j = j0; j < j0 + 8; ++j) row[j] = F[li + min(j, w - 1) * ld];
-                    if (KIND == CS3_LU) {
-#pragma unroll
-                        for (int j = j0; j < j0 + 8; ++j) ut[j] = F[min(j, w - 1) + cj * ld];
-                    }
                 }
             CS3_STAMP(3);
-            sub_eliminate<KIND, false, KIND == CS3_LU>(row, unused, w, w, inv_tol, suspect, ut);
-            // what the tiles read goes back into the image: L21 and U12
-            if (has_parent) {
-                if (live && lane >= w) {
+            if (split) sub_eliminate<KIND, false, false>(row, unused, w, w, inv_tol, suspect, ut);
+            else sub_eliminate<KIND, false, KIND == CS3_LU>(row, unused, w, w, inv_tol, suspect, ut);
+            // what the tiles read goes back into the image: L21 ...
+            if (has_parent && live && lane >= w) {
 #pragma unroll
-                    for (int j0 = 0; j0 < NC; j0 += 8)
-                        if (j0 < w) {
+                for (int j0 = 0; j0 < NC; j0 += 8)
+                    if (j0 < w) {
 #pragma unroll
-                            for (int j = j0; j < j0 + 8; ++j)
-                                if (j < w) F[lane + j * ld] = row[j];
-                        }
-                }
-                if (is_ucol) {
-#pragma unroll
-                    for (int j0 = 0; j0 < NC; j0 += 8)
-                        if (j0 < w) {
-#pragma unroll
-                            for (int j = j0; j < j0 + 8; ++j)
-                                if (j < w) F[j + (w + lane) * ld] = ut[j];
-                        }
-                }
+                        for (int j = j0; j < j0 + 8; ++j)
+                            if (j < w) F[lane + j * ld] = row[j];
+                    }
             }
+        } else if (split && wave == 1) {
+            rows_eliminate_lu(ut, w);
+        }
+        if (KIND == CS3_LU && wave == uwave && has_parent && is_ucol) {         // ... and U12
+#pragma unroll
+            for (int j0 = 0; j0 < NC; j0 += 8)
+                if (j0 < w) {
+#pragma unroll
+                    for (int j = j0; j < j0 + 8; ++j)
+                        if (j < w) F[j + ucol * ld] = ut[j];
+                }
         }
         if (blockDim.x > 64) __syncthreads(); else __builtin_amdgcn_wave_barrier();
         CS3_STAMP(4);
@@ -576,6 +587,18 @@ front_wave_body(const FrontDesc &d, int first, double *F,
             schur_tiles<KIND>(F, ld, r, w, nwv - 1 - wave, nwv, [&](int i, int c, double v) {
                 if (KIND == CS3_LU || i >= c) cbg[(i - w) * mul + (c - w) * sj] = v;
             });
+        }
+        if (KIND == CS3_LU && wave == uwave && is_ucol) {
+            const int mul = d.upan < il.len ? 64 : 1;
+            double *Up = home((int) d.upan) + (ucol - w) * d.u_sj * mul;
+            const int sk = d.u_sk * mul;
+#pragma unroll
+            for (int j0 = 0; j0 < NC; j0 += 8)
+                if (j0 < w) {
+#pragma unroll
+                    for (int j = j0; j < j0 + 8; ++j)
+                        if (j < w) Up[j * sk] = ut[j];
+                }
         }
         if (wave == 0) {
             // the panels: one lane-dependent region per destination, groups of eight register columns behind one
@@ -593,18 +616,6 @@ front_wave_body(const FrontDesc &d, int first, double *F,
                                 if (KIND == CS3_LU) Lp[j * sj] = row[j];
                                 else if (lane >= j) Lp[j * sj] = row[j];
                             }
-                    }
-            }
-            if (is_ucol) {
-                const int mul = d.upan < il.len ? 64 : 1;
-                double *Up = home((int) d.upan) + lane * d.u_sj * mul;
-                const int sk = d.u_sk * mul;
-#pragma unroll
-                for (int j0 = 0; j0 < NC; j0 += 8)
-                    if (j0 < w) {
-#pragma unroll
-                        for (int j = j0; j < j0 + 8; ++j)
-                            if (j < w) Up[j * sk] = ut[j];
                     }
             }
             if (__any(suspect & live)) {                        // rare: find the first rejected column
@@ -844,6 +855,8 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
 
     bool bad = false;
     int bad_col = 0;
+    long long t_ph[3] = {0, 0, 0}, t_last = tbuf ? (long long) __builtin_amdgcn_s_memtime() : 0;
+#define CS3_PHASE(p) do { if (tbuf) { const long long t_now = (long long) __builtin_amdgcn_s_memtime(); t_ph[p] += t_now - t_last; t_last = t_now; } } while (0)
     for (int kb = 0; kb < w; kb += NBK) {
         const int bw = min(NBK, w - kb), ke = kb + bw, nrem = r - ke;
         // ---- 1. the block and its panels: one stacked elimination per wave (at most 128 rows / columns lie
@@ -867,6 +880,7 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
             }
         }
         __syncthreads();                                    // everybody has read D before wave 0 writes its factors back
+        CS3_PHASE(0);
         if (active) {
             eliminate_block<KIND, NBK>(e, row_wave);
             // pivots and multipliers, then home into the image
@@ -898,6 +912,7 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
             }
         }
         __syncthreads();
+        CS3_PHASE(1);
         // ---- 2. trailing update by MFMA, operands from the image: 16 x 16 tiles of F22 dealt to the 8 waves
         if (nrem > 0) {
             const int nt = (nrem + 15) / 16, mi = lane & 15, mq = lane >> 4;
@@ -931,6 +946,12 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
             }
         }
         __syncthreads();
+        CS3_PHASE(2);
+    }
+#undef CS3_PHASE
+    if (tbuf && threadIdx.x == 0) {                        // (diagnostics: block loads / eliminations + write-back / updates)
+        tbuf[(long long) (first + blockIdx.x) * 8 + 6] = t_ph[1];
+        tbuf[(long long) (first + blockIdx.x) * 8 + 7] = t_ph[2];
     }
     CS3_STAMP(3);
     CS3_STAMP(4);

@@ -32,7 +32,8 @@ for l in range(int(lvl.max()) + 1):
         mm = msk & (fr > lo) & (fr <= hi)
         if mm.sum():
             print("level %d r in (%d, %d]: %4d fronts, median r %3d w %3d, median cycles" % (l, lo, hi, mm.sum(), np.median(fr[mm]), np.median(fw[mm])),
-                  dict(zip(names, np.median(d[mm], axis=0).astype(int))), "total", int(np.median(out[mm, 5])))
+                  dict(zip(names, np.median(d[mm], axis=0).astype(int))), "total", int(np.median(out[mm, 5])),
+                  "block kernel: eliminations %d updates %d" % (np.median(out[mm, 6]), np.median(out[mm, 7])) if lo >= 64 else "")
 big = np.flatnonzero((fr > 136) & (out[:, 5] > 0))
 for j in big:
     print("wg front r,w =", fr[j], fw[j], "raw stamps", out[j])

@@ -2591,7 +2591,7 @@ k_front_il(const FrontDesc *__restrict__ fdesc, int first, const int *__restrict
 // (Round 2a walked the backward sweep by columns: r steps, each waiting for its own loads -- 68 us for one front of
 // order 30.)  RMAX bounds the front order (LDS: RMAX * 512 bytes per wave).
 template <int KIND, int RMAX>
-__global__ void __launch_bounds__(64, (RMAX <= 16) ? 3 : 2)
+__global__ void __launch_bounds__(64, 2)
 k_fwd_il(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ rl, IlView il,
          double *cv_all, double *X_all, int nrhs, long long cv_stride, long long x_stride, int batch)
 {

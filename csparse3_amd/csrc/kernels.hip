@@ -755,7 +755,7 @@ k_big_gather(const FrontDesc *__restrict__ fdesc, int first, int kind,
 //     the tile; the multiplier t_k / u_kk drives the updates but the entry that is kept is t_k
 //     itself, which is U(k, column) for the unit-lower solve  L_D u = t.
 template <int KIND, int NBK>
-__device__ __forceinline__ void eliminate_block(double (&d)[NBK], bool keep_unscaled)
+__device__ __forceinline__ void eliminate_block(double (&d)[NBK], bool keep_unscaled, int nsteps = NBK)
 {
     constexpr int EB = 8;                       // columns whose broadcasts are issued together
     const int lane = threadIdx.x & 63;
@@ -765,6 +765,7 @@ __device__ __forceinline__ void eliminate_block(double (&d)[NBK], bool keep_unsc
     pivot_scale<KIND>(piv, dg, rp);
 #pragma unroll
     for (int k = 0; k < NBK; ++k) {
+        if (k < nsteps) {                       // (wave-uniform: the identity-padded steps of a short block do nothing)
         const bool below = lane > k;
         const double l = below ? d[k] * rp : 0.0;
         if (below && !(keep_unscaled && stacked)) d[k] = l;
@@ -793,6 +794,7 @@ __device__ __forceinline__ void eliminate_block(double (&d)[NBK], bool keep_unsc
                     else d[j] -= l * bc[u];                                         // L(j, k): lane j, register k
                 }
             }
+        }
         }
     }
 }
@@ -857,8 +859,14 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
     int bad_col = 0;
     long long t_ph[3] = {0, 0, 0}, t_last = tbuf ? (long long) __builtin_amdgcn_s_memtime() : 0;
 #define CS3_PHASE(p) do { if (tbuf) { const long long t_now = (long long) __builtin_amdgcn_s_memtime(); t_ph[p] += t_now - t_last; t_last = t_now; } } while (0)
-    for (int kb = 0; kb < w; kb += NBK) {
-        const int bw = min(NBK, w - kb), ke = kb + bw, nrem = r - ke;
+    // Blocks of equal width (17 pivots: 9 + 8, not 16 + 1 -- a block step costs its eliminations whatever it holds).  Inside
+    // the loop only the REMAINING PIVOT columns and rows are updated; the contribution block is formed once, after the
+    // last block, from all w pivots and goes straight to the parent's buffer (step 3): it used to be read and written in
+    // the LDS image once per block step, and copied out at the end.
+    const bool has_parent = d.parent >= 0;
+    const int nblk = (w + NBK - 1) / NBK, bsz = (w + nblk - 1) / nblk;
+    for (int kb = 0; kb < w; kb += bsz) {
+        const int bw = min(bsz, w - kb), ke = kb + bw, nrem = r - ke;
         // ---- 1. the block and its panels: one stacked elimination per wave (at most 128 rows / columns lie
         // beyond a block: the analysis sends the rare front that would need a fifth group to the big-front class)
         const bool row_wave = wv >= 4;                      // D' with columns of the block row stacked (LU only)
@@ -882,7 +890,7 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
         __syncthreads();                                    // everybody has read D before wave 0 writes its factors back
         CS3_PHASE(0);
         if (active) {
-            eliminate_block<KIND, NBK>(e, row_wave);
+            eliminate_block<KIND, NBK>(e, row_wave, bw);
             // pivots and multipliers, then home into the image
 #pragma unroll
             for (int j = 0; j < NBK; ++j) {
@@ -914,11 +922,15 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
         __syncthreads();
         CS3_PHASE(1);
         // ---- 2. trailing update by MFMA, operands from the image: 16 x 16 tiles of F22 dealt to the 8 waves
-        if (nrem > 0) {
+        if (nrem > 0 && ke < w) {
             const int nt = (nrem + 15) / 16, mi = lane & 15, mq = lane >> 4;
-            for (int t = wv; t < nt * nt; t += NW) {
-                const int ti = t % nt, tj = t / nt;             // tile rows ke + 16 ti.., columns ke + 16 tj..
-                if (KIND == CS3_CHOLESKY && ti < tj) continue;
+            int turn = 0;                                       // (tiles dealt round-robin; no division in the walk)
+            for (int tj = 0; tj < nt; ++tj)
+              for (int ti = (KIND == CS3_CHOLESKY) ? tj : 0; ti < nt; ++ti) {     // tile rows ke + 16 ti.., columns ke + 16 tj..
+                if (ke + 16 * ti >= w && ke + 16 * tj >= w) continue;      // inside the contribution block: step 3
+                const bool my_turn = turn == wv;
+                turn = (turn + 1 == NW) ? 0 : turn + 1;
+                if (!my_turn) continue;
                 const int i = ke + 16 * ti + mi;                // my row (B operand / output lanes % 16)
                 double4_t acc;
 #pragma unroll
@@ -941,12 +953,50 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int c = ke + 16 * tj + mq + 4 * v;
-                    if (i < r && c < r && (KIND == CS3_LU || i >= c)) F[at(i, c)] = acc[v];
+                    if (i < r && c < r && (i < w || c < w) && (KIND == CS3_LU || i >= c)) F[at(i, c)] = acc[v];
                 }
             }
         }
         __syncthreads();
         CS3_PHASE(2);
+    }
+    // ---- 3. the contribution block:  C(i, j) = F(i, j) - sum_{k < w} L(i, k) U(k, j)  for i, j >= w, by MFMA from the
+    // image (whose pivot columns and rows are final), in pivot order like the block-wise updates it replaces
+    if (has_parent && nb > 0) {
+        double *cb = pool + d.cb;
+        const int nt = (nb + 15) / 16, mi = lane & 15, mq = lane >> 4;
+        int turn = 0;
+        for (int tj = 0; tj < nt; ++tj)
+          for (int ti = (KIND == CS3_CHOLESKY) ? tj : 0; ti < nt; ++ti) {
+            const bool my_turn = turn == wv;
+            turn = (turn + 1 == NW) ? 0 : turn + 1;
+            if (!my_turn) continue;
+            const int i = w + 16 * ti + mi, ca = w + 16 * tj + mi;
+            double4_t acc;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int c = w + 16 * tj + mq + 4 * v;
+                const bool in = i < r && c < r && (KIND == CS3_LU || i >= c);
+                acc[v] = F[in ? at(i, c) : img];
+            }
+            for (int k0 = 0; k0 < w; k0 += 16) {                // sixteen pivots per pass: their operands first, then four MFMAs
+                double au[4], bl[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + 4 * u + mq;
+                    const bool kin = k < w;
+                    au[u] = F[(kin && ca < r) ? ((KIND == CS3_LU) ? k + ca * ld : at(ca, k)) : img];
+                    bl[u] = -F[(kin && i < r) ? at(i, k) : img];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(au[u], bl[u], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int c = w + 16 * tj + mq + 4 * v;
+                if (i < r && c < r && (KIND == CS3_LU || i >= c)) cb[(i - w) + (c - w) * nb] = acc[v];
+            }
+        }
     }
 #undef CS3_PHASE
     if (tbuf && threadIdx.x == 0) {                        // (diagnostics: block loads / eliminations + write-back / updates)
@@ -959,8 +1009,6 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
     // ---- store: L panel, U panel, contribution block
     double *L = pool + d.lpan;
     double *U = pool + d.upan;
-    double *cb = pool + d.cb;
-    const bool has_parent = d.parent >= 0;
     for (int e = tid; e < r * w; e += NW * 64) {                    // L panel, column-major r x w
         const int i = e % r, j = e / r;
         if (KIND == CS3_LU || i >= j) L[e] = F[at(i, j)];
@@ -969,11 +1017,6 @@ k_front_block(const FrontDesc *__restrict__ fdesc, int first,
         for (int e = tid; e < w * nb; e += NW * 64) {               // U panel: pivot rows contiguous (u_sk = 1, u_sj = w)
             const int i = e % w, j = e / w;
             U[(long long) j * d.u_sj + (long long) i * d.u_sk] = F[i + (w + j) * ld];
-        }
-    if (has_parent)
-        for (int e = tid; e < nb * nb; e += NW * 64) {
-            const int i = e % nb, j = e / nb;
-            if (KIND == CS3_LU || i >= j) cb[e] = F[at(w + i, w + j)];
         }
     CS3_STAMP(5);
 #undef CS3_STAMP

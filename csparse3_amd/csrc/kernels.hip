@@ -1064,7 +1064,14 @@ k_front_wg(const FrontDesc *__restrict__ fdesc, int first,
     double *Up = Lp + NB * pld;            // Up[k * pld + j] = U(kb + k, ke + j)   (LU only)
 
     // ---- assemble: zero the buffer, then F = sum of sources (A entries, children's contribution blocks)
-    for (long long e = tid; e < (long long) r * r; e += 512) F[e] = 0.0;
+    if (KIND == CS3_LU) {
+        for (long long e = tid; e < (long long) r * r; e += 512) F[e] = 0.0;
+    } else {
+        // Cholesky never reads an entry above the diagonal for a result it keeps (what the eliminations and updates
+        // compute there stays there): half the buffer need not be written
+        for (int j = wv; j < r; j += 8)
+            for (int i = j + lane; i < r; i += 64) F[i + (long long) j * ld] = 0.0;
+    }
     __syncthreads();
     CS3_WSTAMP(0);
     assemble_extend_add<KIND>(d, al, ax, pool, pil, il.len, tid, 512,

@@ -522,8 +522,9 @@ def main():
                        "parallelism": "independent matrices per rank, no collective (a single factorisation stays on "
                                       "one GPU); the sharding configurations are under `configs`"},
             "roofline": {"bound": "hbm",
-                         "kernel": "numeric factorisation = one hipGraph of k_front_mix / k_front_block / k_big_gather / "
-                                   "k_big_step launches (per tree level; one per block step of a big front)",
+                         "kernel": "numeric factorisation = one hipGraph: k_sub_factor (the bottom forest: subtrees of fronts of "
+                                   "order <= 32, one workgroup per task, one launch), then per tree level k_front_mix / "
+                                   "k_front_block / k_big_gather + k_big_step (one launch per 32-pivot block step of a big front)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "frac_of_measured_peak": achieved / HBM_MEASURED_GBS,
@@ -532,7 +533,8 @@ def main():
                          "avg_launch_ms": t_factor_ms,
                          "measured": "HIP events around the stand-alone factorisation graph, %d launches right after "
                                      "the timed region (inside the fused step the forward sweep overlaps it)" % nphase,
-                         "note": "dependency-depth bound: %d tree levels per factorisation" % int(info.nlevels)},
+                         "note": "dependency-depth bound: %d tree levels per factorisation (the lowest of them inside the "
+                                 "forest launch)" % int(info.nlevels)},
             "phases": {"factor_ms": t_factor_ms, "solve_ms": t_solve_ms,
                        "two_call_step_ms": t_factor_ms + t_solve_ms,
                        "factor_nnz_per_s": nnz_lu / (t_factor_ms * 1e-3),

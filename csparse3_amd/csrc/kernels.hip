@@ -1282,22 +1282,26 @@ k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__res
     const int col0 = (bj == 0) ? kb : ke + (bj - 1) * 64, ncol = (bj == 0) ? bw : min(64, r - col0);
     const bool needs_d = has_panel && (bi == 0 || bj == 0);
 
-    // ---- every global load of this tile goes out before the first LDS store: one round trip
+    // ---- every global load of this tile goes out before anything waits for one: ONE round trip.  The loads are RAW
+    // (from a safe address where the entry does not exist); their masks are applied where the values are used -- with
+    // the select next to the load the compiler waited for the panel operands and stored them to LDS before it issued the
+    // loads of the accumulators (two round trips; stamps: 4.9 k cycles until "loads issued").
+    auto raw = [](const double *__restrict__ p, long long off, bool ok) -> double { return p[ok ? off : 0]; };
     double ra[8], rb[8], rad[4], rbd[4];
     if (kb > 0) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int e = tid + 256 * q;
-            { const int i = e % 64, k = e / 64; ra[q] = load_if(F, (row0 + i) + (long long) (kp + k) * ld, k < pw && i < nrow); }
-            if (KIND == CS3_LU) { const int k = e % BIG_NB, j = e / BIG_NB; rb[q] = load_if(F, (kp + k) + (long long) (col0 + j) * ld, k < pw && j < ncol); }
-            else { const int j = e % 64, k = e / 64; rb[q] = load_if(F, (col0 + j) + (long long) (kp + k) * ld, k < pw && j < ncol); }
+            { const int i = e % 64, k = e / 64; ra[q] = raw(F, (row0 + i) + (long long) (kp + k) * ld, k < pw && i < nrow); }
+            if (KIND == CS3_LU) { const int k = e % BIG_NB, j = e / BIG_NB; rb[q] = raw(F, (kp + k) + (long long) (col0 + j) * ld, k < pw && j < ncol); }
+            else { const int j = e % 64, k = e / 64; rb[q] = raw(F, (col0 + j) + (long long) (kp + k) * ld, k < pw && j < ncol); }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int e = tid + 256 * q;
-            { const int i = e % BIG_NB, k = e / BIG_NB; rad[q] = load_if(F, (kb + i) + (long long) (kp + k) * ld, needs_d && k < pw && i < bw); }
-            if (KIND == CS3_LU) { const int k = e % BIG_NB, j = e / BIG_NB; rbd[q] = load_if(F, (kp + k) + (long long) (kb + j) * ld, needs_d && k < pw && j < bw); }
-            else { const int j = e % BIG_NB, k = e / BIG_NB; rbd[q] = load_if(F, (kb + j) + (long long) (kp + k) * ld, needs_d && k < pw && j < bw); }
+            { const int i = e % BIG_NB, k = e / BIG_NB; rad[q] = raw(F, (kb + i) + (long long) (kp + k) * ld, needs_d && k < pw && i < bw); }
+            if (KIND == CS3_LU) { const int k = e % BIG_NB, j = e / BIG_NB; rbd[q] = raw(F, (kp + k) + (long long) (kb + j) * ld, needs_d && k < pw && j < bw); }
+            else { const int j = e % BIG_NB, k = e / BIG_NB; rbd[q] = raw(F, (kb + j) + (long long) (kp + k) * ld, needs_d && k < pw && j < bw); }
         }
     }
     // my outputs, in the register layout of v_mfma_f64_16x16x4 with the tile transposed (A operand = U
@@ -1311,28 +1315,42 @@ k_big_step(const FrontDesc *__restrict__ fdesc, int first, int kb, double *__res
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int j = 16 * cb + mq + 4 * v;
-            acc[cb][v] = load_if(F, (row0 + ti) + (long long) (col0 + j) * ld, ti < nrow && j < ncol);
+            acc[cb][v] = raw(F, (row0 + ti) + (long long) (col0 + j) * ld, ti < nrow && j < ncol);
         }
     // D, same scheme: wave wv owns the 16 x 16 sub-block (wv & 1, wv >> 1): dacc[v] = D(dr, dc0 + 4 v)
     const int dr = 16 * (wv & 1) + mi, dc0 = 16 * (wv >> 1) + mq;
     double4_t dacc;
 #pragma unroll
     for (int v = 0; v < 4; ++v)
-        dacc[v] = load_if(F, (kb + dr) + (long long) (kb + dc0 + 4 * v) * ld, needs_d && dr < bw && dc0 + 4 * v < bw);
+        dacc[v] = raw(F, (kb + dr) + (long long) (kb + dc0 + 4 * v) * ld, needs_d && dr < bw && dc0 + 4 * v < bw);
+    __builtin_amdgcn_sched_barrier(0);
     CS3_BSTAMP(0);
+    // (the masks now)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int j = 16 * cb + mq + 4 * v;
+            if (!(ti < nrow && j < ncol)) acc[cb][v] = 0.0;
+        }
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+        if (!(needs_d && dr < bw && dc0 + 4 * v < bw)) dacc[v] = 0.0;
     if (kb > 0) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int e = tid + 256 * q;
-            As[e / 64][e % 64] = -ra[q];                  // negated: the MFMA accumulates acc += U' (-L)'
-            if (KIND == CS3_LU) Bs[e % BIG_NB][e / BIG_NB] = rb[q]; else Bs[e / 64][e % 64] = rb[q];
+            { const int i = e % 64, k = e / 64; As[e / 64][e % 64] = (k < pw && i < nrow) ? -ra[q] : 0.0; }     // negated: the MFMA accumulates acc += U' (-L)'
+            if (KIND == CS3_LU) { const int k = e % BIG_NB, j = e / BIG_NB; Bs[k][j] = (k < pw && j < ncol) ? rb[q] : 0.0; }
+            else { const int j = e % 64, k = e / 64; Bs[k][j] = (k < pw && j < ncol) ? rb[q] : 0.0; }
         }
         if (needs_d) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int e = tid + 256 * q;
-                Ad[e / BIG_NB][e % BIG_NB] = -rad[q];
-                if (KIND == CS3_LU) Bd[e % BIG_NB][e / BIG_NB] = rbd[q]; else Bd[e / BIG_NB][e % BIG_NB] = rbd[q];
+                { const int i = e % BIG_NB, k = e / BIG_NB; Ad[k][i] = (k < pw && i < bw) ? -rad[q] : 0.0; }
+                if (KIND == CS3_LU) { const int k = e % BIG_NB, j = e / BIG_NB; Bd[k][j] = (k < pw && j < bw) ? rbd[q] : 0.0; }
+                else { const int j = e % BIG_NB, k = e / BIG_NB; Bd[k][j] = (k < pw && j < bw) ? rbd[q] : 0.0; }
             }
         }
     }

@@ -717,18 +717,30 @@ k_big_gather(const FrontDesc *__restrict__ fdesc, int first, int kind,
     }
     __syncthreads();
     const int4 *tab = (const int4 *) al.ch_tab + d.ch_begin;
+    int4 ce_next = (d.ch_count > 0) ? tab[0] : int4{0, 0, 0, 0};
     for (int c = 0; c < d.ch_count; ++c) {
-        const int4 ce = tab[c];
+        const int4 ce = ce_next;
+        if (c + 1 < d.ch_count) ce_next = tab[c + 1];           // the next child's entry travels while this one is added
         const int nbc = ce.x, cbo = ce.z, cld = ce.w;
         const int *__restrict__ rel = al.rel_idx + ce.y;
         const bool inter = cbo < il.len;
-        // first child column at or beyond c_lo / c_hi (binary searches, the same in every thread)
-        auto first_at = [&](int from, int bound) {
-            int lo = from, hi = nbc;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (rel[mid] < bound) lo = mid + 1; else hi = mid; }
-            return lo;
-        };
-        const int j0 = first_at(0, c_lo), j1 = first_at(j0, c_hi);
+        // first child column at or beyond c_lo / c_hi: every wave COUNTS the map entries below the bound (one round of
+        // loads, a ballot per 64 entries) -- a binary search is log2(nbc) dependent round trips, twice per child
+        int j0 = 0, j1 = 0;
+        for (int base = 0; base < nbc; base += 256) {
+            int rv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = base + 64 * u + lane;
+                rv[u] = rel[e < nbc ? e : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in = base + 64 * u + lane < nbc;
+                j0 += __popcll(__builtin_amdgcn_ballot_w64(in && rv[u] < c_lo));
+                j1 += __popcll(__builtin_amdgcn_ballot_w64(in && rv[u] < c_hi));
+            }
+        }
         for (int jj = j0 + wv; jj < j1; jj += 4) {
             const long long cj = (long long) rel[jj] * r;
             for (int ii = lane; ii < nbc; ii += 64) {

@@ -2935,8 +2935,24 @@ __device__ __forceinline__ void gemm64(const double *As, const double *Bs, doubl
     }
 }
 
+// The same product by EIGHT waves (two per SIMD: a wave issues one f64 MFMA per 64 cycles, two interleave to 32): wave
+// (rb, ch) owns rows 16 rb .. 16 rb + 15 and right-hand sides 32 ch .. 32 ch + 31, acc[t][v] = entry
+// (16 rb + mq + 4 v, 16 (2 ch + t) + mi).
+template <bool NEG>
+__device__ __forceinline__ void gemm64h(const double *As, const double *Bs, double4_t (&acc)[2], int rb, int ch, int mi, int mq)
+{
+#pragma unroll
+    for (int k0 = 0; k0 < GC; k0 += 4) {
+        const double a0 = As[(k0 + mq) * GLD + 16 * rb + mi];
+        const double a = NEG ? -a0 : a0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[(k0 + mq) * GLD + 16 * (2 * ch + t) + mi], acc[t], 0, 0, 0);
+    }
+}
+
 template <int KIND>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 k_gemm_fwd(const SolveDesc *__restrict__ sd, int first, int c,
            const double *__restrict__ pool_all, const double *__restrict__ dinv_all, double *__restrict__ cv_all,
            double *__restrict__ X_all, double *__restrict__ gv_all, int nrhs, long long pool_stride, long long dinv_stride,
@@ -2955,77 +2971,77 @@ k_gemm_fwd(const SolveDesc *__restrict__ sd, int first, int c,
     const double *L = pool_all + (long long) b * pool_stride + d.lpan;
     const double *Linv = dinv_all + (long long) b * dinv_stride + d.dinv + (long long) c * 2 * GC * GC;
     double *V = gv_all + (long long) b * gv_stride + d.gv * (long long) nrhs;                 // V[row * nrhs + rhs]
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, mi = lane & 15, mq = lane >> 4;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, mi = lane & 15, mq = lane >> 4, rbk = wv & 3, ch = wv >> 2;
     // every global load of the workgroup goes out first (one round trip): the inverse, the chunk's rows of V, my
     // slice of the panel and my rows of V
     const bool has_rows = nsl > 0;
     const int row0 = ke + blockIdx.x * GC;
-    double ra[16], rb[16], rl[16];
+    double ra[8], rb[16], rl[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int e = tid + 256 * q, k = e >> 6, i = e & 63;
+    for (int q = 0; q < 8; ++q) {
+        const int e = tid + 512 * q, k = e >> 6, i = e & 63;
         ra[q] = Linv[e];
         rb[q] = load_if(V, (long long) (kb + k) * nrhs + n0 + i, k < bw && i < nlive);
         rl[q] = load_if(L, (long long) (row0 + i) + (long long) (kb + k) * r, has_rows && row0 + i < r && k < bw);
     }
-    double4_t acc2[4];
+    double4_t acc2[2];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const int row = row0 + 16 * wv + mq + 4 * v, n = 16 * nt + mi;
-            acc2[nt][v] = load_if(V, (long long) row * nrhs + n0 + n, has_rows && row < r && n < nlive);
+            const int row = row0 + 16 * rbk + mq + 4 * v, n = 16 * (2 * ch + t) + mi;
+            acc2[t][v] = load_if(V, (long long) row * nrhs + n0 + n, has_rows && row < r && n < nlive);
         }
     // ---- Y = Linv_cc V_c
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int e = tid + 256 * q, k = e >> 6, i = e & 63;
+    for (int q = 0; q < 8; ++q) {
+        const int e = tid + 512 * q, k = e >> 6, i = e & 63;
         As[k * GLD + i] = ra[q];
         Bs[k * GLD + i] = rb[q];
     }
     __syncthreads();
-    double4_t acc[4];
+    double4_t acc[2];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) acc[nt] = double4_t{0.0, 0.0, 0.0, 0.0};
-    gemm64<false>(As, Bs, acc, wv, mi, mq);
+    for (int t = 0; t < 2; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+    gemm64h<false>(As, Bs, acc, rbk, ch, mi, mq);
     __syncthreads();
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) Bs[(16 * wv + mq + 4 * v) * GLD + 16 * nt + mi] = acc[nt][v];     // Y(k, n)
+        for (int v = 0; v < 4; ++v) Bs[(16 * rbk + mq + 4 * v) * GLD + 16 * (2 * ch + t) + mi] = acc[t][v];     // Y(k, n)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int e = tid + 256 * q, k = e >> 6, i = e & 63;
+    for (int q = 0; q < 8; ++q) {
+        const int e = tid + 512 * q, k = e >> 6, i = e & 63;
         As[k * GLD + i] = rl[q];                                                                     // L(row0 + i, kb + k)
     }
     __syncthreads();
     if (blockIdx.x == 0) {
         double *X = X_all + (long long) b * x_stride;
-        for (int e = tid; e < GC * GC; e += 256) {
+        for (int e = tid; e < GC * GC; e += 512) {
             const int k = e >> 6, n = e & 63;
             if (k < bw && n < nlive) X[(long long) (d.c0 + kb + k) * nrhs + n0 + n] = Bs[k * GLD + n];
         }
     }
     if (!has_rows) return;
     // ---- my 64 rows below the chunk:  V_rows -= L(rows, chunk) Y
-    gemm64<true>(As, Bs, acc2, wv, mi, mq);
+    gemm64h<true>(As, Bs, acc2, rbk, ch, mi, mq);
     const bool last = ke >= w && d.parent >= 0;             // rows below the pivots are final: the parent's input
     double *cv = cv_all + (long long) b * cv_stride;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const int row = row0 + 16 * wv + mq + 4 * v, n = 16 * nt + mi;
+            const int row = row0 + 16 * rbk + mq + 4 * v, n = 16 * (2 * ch + t) + mi;
             if (row < r && n < nlive) {
-                V[(long long) row * nrhs + n0 + n] = acc2[nt][v];
-                if (last) cv[(d.cv + row - w) * nrhs + n0 + n] = acc2[nt][v];
+                V[(long long) row * nrhs + n0 + n] = acc2[t][v];
+                if (last) cv[(d.cv + row - w) * nrhs + n0 + n] = acc2[t][v];
             }
         }
 }
 
 // V(pivot rows) = X(pivot rows) - U12 X(ancestors' rows): one workgroup per 64 pivot rows and tile of 64 right-hand sides
 template <int KIND>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 k_gemm_bwd_init(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ st_idx,
                 const double *__restrict__ pool_all, const double *__restrict__ X_all, double *__restrict__ gv_all,
                 int nrhs, long long pool_stride, long long x_stride, long long gv_stride, int batch)
@@ -3042,27 +3058,27 @@ k_gemm_bwd_init(const SolveDesc *__restrict__ sd, int first, const int *__restri
     const double *X = X_all + (long long) b * x_stride;
     double *V = gv_all + (long long) b * gv_stride + d.gv * (long long) nrhs;
     const int *st = st_idx + d.st;
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, mi = lane & 15, mq = lane >> 4;
-    double4_t acc[4];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, mi = lane & 15, mq = lane >> 4, rbk = wv & 3, ch = wv >> 2;
+    double4_t acc[2];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const int i = i0 + 16 * wv + mq + 4 * v, n = 16 * nt + mi;
-            acc[nt][v] = load_if(X, (long long) (d.c0 + i) * nrhs + n0 + n, i < w && n < nlive);
+            const int i = i0 + 16 * rbk + mq + 4 * v, n = 16 * (2 * ch + t) + mi;
+            acc[t][v] = load_if(X, (long long) (d.c0 + i) * nrhs + n0 + n, i < w && n < nlive);
         }
     for (int jb = 0; jb < nb; jb += GC) {
         // all 32 global loads of a thread go out together (the ancestors' row numbers one round trip ahead of their rows)
-        int arow[16];
+        int arow[8];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int k = (tid >> 6) + 4 * q;
+        for (int q = 0; q < 8; ++q) {
+            const int k = (tid >> 6) + 8 * q;
             arow[q] = st[(jb + k < nb) ? w + jb + k : 0];
         }
-        double ua[16], xb[16];
+        double ua[8], xb[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int e = tid + 256 * q;
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + 512 * q;
             {   // As[k][i] = U(i0 + i, w + jb + k)
                 const int k = (KIND == CS3_LU) ? e >> 6 : e & 63, i = (KIND == CS3_LU) ? e & 63 : e >> 6;
                 const bool in = i0 + i < w && jb + k < nb;
@@ -3077,26 +3093,26 @@ k_gemm_bwd_init(const SolveDesc *__restrict__ sd, int first, const int *__restri
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int e = tid + 256 * q;
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + 512 * q;
             const int k = (KIND == CS3_LU) ? e >> 6 : e & 63, i = (KIND == CS3_LU) ? e & 63 : e >> 6;
             As[k * GLD + i] = ua[q];
             Bs[(e >> 6) * GLD + (e & 63)] = xb[q];
         }
         __syncthreads();
-        gemm64<true>(As, Bs, acc, wv, mi, mq);
+        gemm64h<true>(As, Bs, acc, rbk, ch, mi, mq);
     }
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const int i = i0 + 16 * wv + mq + 4 * v, n = 16 * nt + mi;
-            if (i < w && n < nlive) V[(long long) i * nrhs + n0 + n] = acc[nt][v];
+            const int i = i0 + 16 * rbk + mq + 4 * v, n = 16 * (2 * ch + t) + mi;
+            if (i < w && n < nlive) V[(long long) i * nrhs + n0 + n] = acc[t][v];
         }
 }
 
 template <int KIND>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 k_gemm_bwd(const SolveDesc *__restrict__ sd, int first, int chunk_from_right,
            const double *__restrict__ pool_all, const double *__restrict__ dinv_all, double *__restrict__ X_all,
            double *__restrict__ gv_all, int nrhs, long long pool_stride, long long dinv_stride, long long x_stride,
@@ -3117,13 +3133,13 @@ k_gemm_bwd(const SolveDesc *__restrict__ sd, int first, int chunk_from_right,
     const double *L = pool_all + (long long) b * pool_stride + d.lpan;
     const double *Uinv = dinv_all + (long long) b * dinv_stride + d.dinv + (long long) c * 2 * GC * GC + GC * GC;
     double *V = gv_all + (long long) b * gv_stride + d.gv * (long long) nrhs;
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, mi = lane & 15, mq = lane >> 4;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, mi = lane & 15, mq = lane >> 4, rbk = wv & 3, ch = wv >> 2;
     const bool has_rows = nsl > 0;
     const int row0 = blockIdx.x * GC;
-    double ra[16], rb[16], rl[16];
+    double ra[8], rb[16], rl[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int e = tid + 256 * q;
+    for (int q = 0; q < 8; ++q) {
+        const int e = tid + 512 * q;
         {
             const int k = e >> 6, i = e & 63;
             ra[q] = Uinv[e];
@@ -3136,34 +3152,34 @@ k_gemm_bwd(const SolveDesc *__restrict__ sd, int first, int chunk_from_right,
             rl[q] = load_if(L, off, has_rows && row0 + i < kb && k < bw);
         }
     }
-    double4_t acc2[4];
+    double4_t acc2[2];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const int row = row0 + 16 * wv + mq + 4 * v, n = 16 * nt + mi;
-            acc2[nt][v] = load_if(V, (long long) row * nrhs + n0 + n, has_rows && row < kb && n < nlive);
+            const int row = row0 + 16 * rbk + mq + 4 * v, n = 16 * (2 * ch + t) + mi;
+            acc2[t][v] = load_if(V, (long long) row * nrhs + n0 + n, has_rows && row < kb && n < nlive);
         }
     // ---- Y = Uinv_cc V_c
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int e = tid + 256 * q, k = e >> 6, i = e & 63;
+    for (int q = 0; q < 8; ++q) {
+        const int e = tid + 512 * q, k = e >> 6, i = e & 63;
         As[k * GLD + i] = ra[q];
         Bs[k * GLD + i] = rb[q];
     }
     __syncthreads();
-    double4_t acc[4];
+    double4_t acc[2];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) acc[nt] = double4_t{0.0, 0.0, 0.0, 0.0};
-    gemm64<false>(As, Bs, acc, wv, mi, mq);
+    for (int t = 0; t < 2; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+    gemm64h<false>(As, Bs, acc, rbk, ch, mi, mq);
     __syncthreads();
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) Bs[(16 * wv + mq + 4 * v) * GLD + 16 * nt + mi] = acc[nt][v];
+        for (int v = 0; v < 4; ++v) Bs[(16 * rbk + mq + 4 * v) * GLD + 16 * (2 * ch + t) + mi] = acc[t][v];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int e = tid + 256 * q;
+    for (int q = 0; q < 8; ++q) {
+        const int e = tid + 512 * q;
         const int k = (KIND == CS3_LU) ? e >> 6 : e & 63, i = (KIND == CS3_LU) ? e & 63 : e >> 6;
         As[k * GLD + i] = rl[q];
     }
@@ -3171,7 +3187,7 @@ k_gemm_bwd(const SolveDesc *__restrict__ sd, int first, int chunk_from_right,
     if (blockIdx.x == 0) {
         double *X = X_all + (long long) b * x_stride;
         double *Xo = xm.dst ? xm.dst + (long long) b * x_stride : nullptr;     // fused permutation: row q[k] of the caller's array
-        for (int e = tid; e < GC * GC; e += 256) {
+        for (int e = tid; e < GC * GC; e += 512) {
             const int k = e >> 6, n = e & 63;
             if (k < bw && n < nlive) {
                 X[(long long) (d.c0 + kb + k) * nrhs + n0 + n] = Bs[k * GLD + n];
@@ -3181,13 +3197,13 @@ k_gemm_bwd(const SolveDesc *__restrict__ sd, int first, int chunk_from_right,
     }
     if (!has_rows) return;
     // ---- my 64 pivot rows above the chunk:  V_rows -= U(rows, chunk) Y
-    gemm64<true>(As, Bs, acc2, wv, mi, mq);
+    gemm64h<true>(As, Bs, acc2, rbk, ch, mi, mq);
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const int row = row0 + 16 * wv + mq + 4 * v, n = 16 * nt + mi;
-            if (row < kb && n < nlive) V[(long long) row * nrhs + n0 + n] = acc2[nt][v];
+            const int row = row0 + 16 * rbk + mq + 4 * v, n = 16 * (2 * ch + t) + mi;
+            if (row < kb && n < nlive) V[(long long) row * nrhs + n0 + n] = acc2[t][v];
         }
 }
 
@@ -3804,16 +3820,16 @@ static hipError_t launch_gemm_group(const DeviceFactor &D, const LaunchGroup &g,
                            g.first, D.sl_src, D.cv, X, D.gv, nrhs, cvs, xs, gvs, D.xm, (int) batch);
         CS3_LAUNCH_CHECK();
         for (int c = 0; c < nchunk; ++c) {
-            hipLaunchKernelGGL((k_gemm_fwd<KIND>), dim3(slices, tiles, g.count * batch), dim3(256), GEMM_LDS, st, D.sd(), g.first, c,
+            hipLaunchKernelGGL((k_gemm_fwd<KIND>), dim3(slices, tiles, g.count * batch), dim3(512), GEMM_LDS, st, D.sd(), g.first, c,
                                D.pool_pm, D.dinv, D.cv, X, D.gv, nrhs, D.pm_stride, D.dinv_size, cvs, xs, gvs, (int) batch);
             CS3_LAUNCH_CHECK();
         }
     } else {
-        hipLaunchKernelGGL((k_gemm_bwd_init<KIND>), dim3((unsigned) nchunk, tiles, g.count * batch), dim3(256), GEMM_LDS, st, D.sd(),
+        hipLaunchKernelGGL((k_gemm_bwd_init<KIND>), dim3((unsigned) nchunk, tiles, g.count * batch), dim3(512), GEMM_LDS, st, D.sd(),
                            g.first, D.st_idx, D.pool_pm, X, D.gv, nrhs, D.pm_stride, xs, gvs, (int) batch);
         CS3_LAUNCH_CHECK();
         for (int c = 0; c < nchunk; ++c) {
-            hipLaunchKernelGGL((k_gemm_bwd<KIND>), dim3((unsigned) std::max(1, nchunk), tiles, g.count * batch), dim3(256), GEMM_LDS, st,
+            hipLaunchKernelGGL((k_gemm_bwd<KIND>), dim3((unsigned) std::max(1, nchunk), tiles, g.count * batch), dim3(512), GEMM_LDS, st,
                                D.sd(), g.first, c, D.pool_pm, D.dinv, X, D.gv, nrhs, D.pm_stride, D.dinv_size, xs, gvs, (int) batch, D.xm);
             CS3_LAUNCH_CHECK();
         }

@@ -2976,7 +2976,7 @@ k_gemm_fwd(const SolveDesc *__restrict__ sd, int first, int c,
     // slice of the panel and my rows of V
     const bool has_rows = nsl > 0;
     const int row0 = ke + blockIdx.x * GC;
-    double ra[8], rb[16], rl[16];
+    double ra[8], rb[8], rl[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int e = tid + 512 * q, k = e >> 6, i = e & 63;
@@ -3136,7 +3136,7 @@ k_gemm_bwd(const SolveDesc *__restrict__ sd, int first, int chunk_from_right,
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, mi = lane & 15, mq = lane >> 4, rbk = wv & 3, ch = wv >> 2;
     const bool has_rows = nsl > 0;
     const int row0 = blockIdx.x * GC;
-    double ra[8], rb[16], rl[16];
+    double ra[8], rb[8], rl[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int e = tid + 512 * q;
@@ -4067,6 +4067,43 @@ hipError_t launch_factor_with_forward(const DeviceFactor &D, const std::vector<L
         }
         return hipSuccess;
     };
+    // BATCHES: every level is a launch of 100 us or more, so a cross-queue edge (5-10 us) per level is cheap and the
+    // forward sweep follows the factorisation level by level on fj.aux -- sweep level l as soon as level l is factorised --
+    // instead of waiting for the fork level (round 3; kernel trace of 512 matrices: the sweep of levels 1..9, 400 us of
+    // small launches, ran after the root with nothing beside it).  Sweep level l is CAPTURED after factor level l + 1, so
+    // that the factor chain stays the first captured dependent of its own nodes (see below).
+    if (overlap && D.batch >= 16 && nlevels >= 2) {
+        hipEvent_t pending = nullptr;
+        int pending_level = -1;
+        auto flush = [&]() -> hipError_t {
+            if (!pending) return hipSuccess;
+            hipError_t fe;
+            if ((fe = hipStreamWaitEvent(fj.aux, pending, 0)) != hipSuccess) return fe;
+            fe = sweep(pending_level, pending_level, fj.aux);
+            pending = nullptr;
+            return fe;
+        };
+        for (size_t f0 = 0; f0 < fgroups.size(); ) {
+            const int level = fgroups[f0].level;
+            size_t f1 = f0;
+            while (f1 < fgroups.size() && fgroups[f1].level == level) ++f1;
+            e = run_level(fgroups, f0, f1, st, fj, true, [&](const LaunchGroup &g, hipStream_t s2) {
+                return (D.kind == CS3_LU) ? launch_front_group<CS3_LU>(D, g, inv_tol, s2)
+                                          : launch_front_group<CS3_CHOLESKY>(D, g, inv_tol, s2);
+            });
+            if (e != hipSuccess) return e;
+            if ((e = flush()) != hipSuccess) return e;
+            if ((e = fj.event(&pending)) != hipSuccess) return e;
+            if ((e = hipEventRecord(pending, st)) != hipSuccess) return e;
+            pending_level = level;
+            f0 = f1;
+        }
+        if ((e = flush()) != hipSuccess) return e;
+        hipEvent_t done;
+        if ((e = fj.event(&done)) != hipSuccess) return e;
+        if ((e = hipEventRecord(done, fj.aux)) != hipSuccess) return e;
+        return hipStreamWaitEvent(st, done, 0);
+    }
     // The last level, when it is one group of wide big fronts (the dense root): its forward sweep does not wait
     // for the end of its factorisation either.  Column block b of the factor is final in F after block launch
     // b + 1 (k_big_step), so chunk c of the sweep follows on fj.aux as soon as its blocks are home, while the

@@ -229,7 +229,8 @@ __device__ __forceinline__ void rows_eliminate_lu(double (&ut)[32], int w)
 }
 
 // ---- the trailing matrix of a front whose image lives in LDS (column-major, leading dimension ld), by
-// v_mfma_f64_16x16x4:   C(i, j) - sum_{k < w} L(i, k) U(k, j)   for i, j in [w, r), in 16 x 16 tiles dealt to `nwaves`
+// v_mfma_f64_16x16x4 (entry (i, j) of the image at F[at(i, j)]: column-major, or the packed lower triangle for Cholesky):
+//   C(i, j) - sum_{k < w} L(i, k) U(k, j)   for i, j in [w, r), in 16 x 16 tiles dealt to `nwaves`
 // waves; every entry of the result is handed to out(i, j, value) exactly once (Cholesky: the tiles on and below the
 // diagonal; the caller drops i < j inside a diagonal tile).  L(i, k) = F[i + k ld]; U(k, j) = F[k + j ld] (LU), or
 // L(j, k) (Cholesky).  The sum runs in pivot order with fused multiply-adds, like the column-by-column updates it
@@ -237,8 +238,8 @@ __device__ __forceinline__ void rows_eliminate_lu(double (&ut)[32], int w)
 // reads and one FMA per column and pivot).  Tiles are computed TRANSPOSED (A operand = U, B operand = -L), so that the 16
 // lanes of an output register hold 16 consecutive ROWS of one column: stores to a column-major block coalesce.
 typedef double cs3_double4 __attribute__((ext_vector_type(4)));
-template <int KIND, class Out>
-__device__ __forceinline__ void schur_tiles(const double *F, int ld, int r, int w, int wave, int nwaves, Out out)
+template <int KIND, class At, class Out>
+__device__ __forceinline__ void schur_tiles(const double *F, At at, int r, int w, int wave, int nwaves, Out out)
 {
     const int lane = threadIdx.x & 63, mi = lane & 15, mq = lane >> 4;
     const int nt = (r - w + 15) >> 4;
@@ -252,15 +253,15 @@ __device__ __forceinline__ void schur_tiles(const double *F, int ld, int r, int 
                                                                 //  finite values that only reach outputs nobody takes)
             cs3_double4 acc;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) acc[v] = F[ic + min(w + 16 * tj + mq + 4 * v, r - 1) * ld];
+            for (int v = 0; v < 4; ++v) acc[v] = F[at(ic, min(w + 16 * tj + mq + 4 * v, r - 1))];
 #pragma unroll
             for (int k0 = 0; k0 < 32; k0 += 4) {
                 if (k0 < w) {
                     const int k = k0 + mq;
                     const bool kin = k < w;
                     const int kc = kin ? k : 0;
-                    const double au = F[(KIND == CS3_LU) ? kc + cc * ld : cc + kc * ld];
-                    const double bl = F[ic + kc * ld];
+                    const double au = F[(KIND == CS3_LU) ? at(kc, cc) : at(cc, kc)];
+                    const double bl = F[at(ic, kc)];
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kin ? au : 0.0, kin ? -bl : 0.0, acc, 0, 0, 0);
                 }
             }

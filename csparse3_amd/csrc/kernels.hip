@@ -497,17 +497,30 @@ front_wave_body(const FrontDesc &d, int first, double *F,
     double *pool = pool_all + (long long) blockIdx.y * pool_stride;
     const int r = d.r, w = d.w, nb = r - w;
     const int ld = r | 1;
+    // The image.  LU: column-major with the odd leading dimension ld.  Cholesky: only the lower triangle exists, PACKED by
+    // columns (entry (i, j), i >= j, at i + j (2 r - 1 - j) / 2): half the LDS, so twice the workgroups per CU in a batch
+    // (what is read "above the diagonal" below is some other entry of the image -- finite, and it only reaches results
+    // nobody keeps).
+    const int img = (KIND == CS3_LU) ? r * ld : (r * (r + 1)) >> 1;
+    auto at = [&](int i, int j) -> int { return (KIND == CS3_LU) ? i + j * ld : i + ((j * (2 * r - 1 - j)) >> 1); };
     // a pool offset below il.len lives in the matrix-interleaved region (the panels of a front whose sweeps run lane =
     // matrix): entry `off` of this matrix is pil[off * 64]
     auto home = [&](int off) -> double * { return (off < il.len) ? pil + (long long) off * 64 : pool + off; };
     // four waves assemble the front (the gather is latency-bound: more loads in flight), one eliminates it
     CS3_STAMP(0);
-    for (int i = threadIdx.x; i < r * ld; i += blockDim.x) F[i] = 0.0;
+    for (int i = threadIdx.x; i < img; i += blockDim.x) F[i] = 0.0;
     __syncthreads();
     CS3_STAMP(1);
+    const float inv_ld = 1.0f / (float) ld;
     assemble_extend_add<KIND>(d, al, ax, pool, pil, il.len, (int) threadIdx.x, (int) blockDim.x,
-                              [&](int t, double v) { F[t] = v; },
-                              [&](int i, int j, double v) { front_add(&F[i + j * ld], v); },
+                              [&](int t, double v) {
+                                  if (KIND == CS3_LU) { F[t] = v; return; }
+                                  int j = (int) ((float) t * inv_ld);       // the targets of A's entries are i + j ld: unpack (t < 2^15)
+                                  j += ((j + 1) * ld <= t) ? 1 : 0;
+                                  j -= (j * ld > t) ? 1 : 0;
+                                  F[at(t - j * ld, j)] = v;
+                              },
+                              [&](int i, int j, double v) { front_add(&F[at(i, j)], v); },
                               [&]() { __syncthreads(); });
     CS3_STAMP(2);
     const int lane = threadIdx.x & 63;
@@ -540,7 +553,7 @@ front_wave_body(const FrontDesc &d, int first, double *F,
             for (int j0 = 0; j0 < NC; j0 += 8)
                 if (j0 < w) {
 #pragma unroll
-                    for (int j = j0; j < j0 + 8; ++j) ut[j] = F[min(j, w - 1) + cj * ld];
+                    for (int j = j0; j < j0 + 8; ++j) ut[j] = F[at(min(j, w - 1), cj)];
                 }
         }
         if (wave == 0) {
@@ -549,7 +562,7 @@ front_wave_body(const FrontDesc &d, int first, double *F,
             for (int j0 = 0; j0 < NC; j0 += 8)
                 if (j0 < w) {
 #pragma unroll
-                    for (int j = j0; j < j0 + 8; ++j) row[j] = F[li + min(j, w - 1) * ld];
+                    for (int j = j0; j < j0 + 8; ++j) row[j] = F[at(li, min(j, w - 1))];
                 }
             CS3_STAMP(3);
             if (split) sub_eliminate<KIND, false, false>(row, unused, w, w, inv_tol, suspect, ut);
@@ -561,7 +574,7 @@ front_wave_body(const FrontDesc &d, int first, double *F,
                     if (j0 < w) {
 #pragma unroll
                         for (int j = j0; j < j0 + 8; ++j)
-                            if (j < w) F[lane + j * ld] = row[j];
+                            if (j < w) F[at(lane, j)] = row[j];
                     }
             }
         } else if (split && wave == 1) {
@@ -573,7 +586,7 @@ front_wave_body(const FrontDesc &d, int first, double *F,
                 if (j0 < w) {
 #pragma unroll
                     for (int j = j0; j < j0 + 8; ++j)
-                        if (j < w) F[j + ucol * ld] = ut[j];
+                        if (j < w) F[at(j, ucol)] = ut[j];
                 }
         }
         if (blockDim.x > 64) __syncthreads(); else __builtin_amdgcn_wave_barrier();
@@ -584,7 +597,7 @@ front_wave_body(const FrontDesc &d, int first, double *F,
             const int mul = d.cb < il.len ? 64 : 1;
             double *cbg = home((int) d.cb);
             const int sj = nb * mul;
-            schur_tiles<KIND>(F, ld, r, w, nwv - 1 - wave, nwv, [&](int i, int c, double v) {
+            schur_tiles<KIND>(F, at, r, w, nwv - 1 - wave, nwv, [&](int i, int c, double v) {
                 if (KIND == CS3_LU || i >= c) cbg[(i - w) * mul + (c - w) * sj] = v;
             });
         }
@@ -3526,14 +3539,21 @@ static hipError_t launch_front_group(const DeviceFactor &D, const LaunchGroup &g
     }
     dim3 grid((unsigned) g.count, batch);
     const size_t ld = (size_t) (g.max_r | 1);
-    const size_t lds = (ld * (size_t) g.max_r + 4 * (size_t) g.max_r + 6) * sizeof(double);
+    // (front_wave_body, the path of every front with <= 32 pivots, packs the lower triangle for Cholesky; the 16 x 16 thread
+    //  grid that takes the others keeps the full image)
+    const bool packed = KIND == CS3_CHOLESKY && g.max_w <= 32;
+    const size_t lds = ((packed ? (size_t) g.max_r * (size_t) (g.max_r + 1) / 2 : ld * (size_t) g.max_r) + 4 * (size_t) g.max_r + 6) * sizeof(double);
 #define CS3_FRONT_ARGS D.fdesc, g.first, AsmLists{D.fa_tgt, D.fa_src, D.ch_tab, D.rel_idx}, D.ax, D.pool_pm, D.nnz_a, D.pm_stride, IlView{D.pool_il, D.il_len}, inv_tol, D.status, D.tbuf
     switch (g.cls) {
     case FC_R16:
     case FC_R32:      // only present when the analysis split the small fronts off (batched handles)
         hipLaunchKernelGGL((k_front_wave<KIND>), grid, dim3(64), lds, st, CS3_FRONT_ARGS); break;
-    case FC_R64:      // at most 32 pivots: panel by one wave + Schur complement by MFMA; more: the 16 x 16 thread grid
-        hipLaunchKernelGGL((k_front_mix<KIND>), grid, dim3(256), lds, st, CS3_FRONT_ARGS); break;
+    case FC_R64: {    // at most 32 pivots: panel by one wave + Schur complement by MFMA; more: the 16 x 16 thread grid
+        // a batch fills the chip with fronts, not with waves per front: two waves (panel columns / pivot rows, then the
+        // tiles) instead of four double the fronts per CU -- the image, not the registers, then bounds the occupancy
+        const unsigned threads = (D.batch >= 16 && g.max_w <= 32) ? 128 : 256;
+        hipLaunchKernelGGL((k_front_mix<KIND>), grid, dim3(threads), lds, st, CS3_FRONT_ARGS); break;
+    }
     default:
         // 16 pivots per block step: the one-wave elimination of a block costs NBK^2 column updates, the MFMA update that
         // follows is cheap, so narrow blocks win (measured: 32 -> 16 took 4 % off the batched config, neutral on config 3;

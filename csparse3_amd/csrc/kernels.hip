@@ -1107,6 +1107,106 @@ k_front_wg(const FrontDesc *__restrict__ fdesc, int first,
 
     bool bad = false;
     int bad_col = 0;
+    if (KIND == CS3_CHOLESKY) {
+        // LEFT-LOOKING (round 3).  The right-looking form below reads and writes the whole trailing matrix of the front
+        // -- which lives in global memory here -- once per 16 pivots (1.9 MB per matrix of a 226 x 226 root, every block
+        // step waiting for those round trips).  Here a block column is touched ONCE: its 16-row tiles take
+        //      C(rows, block) -= L(rows, 0:kb) L(block, 0:kb)'
+        // on the matrix cores (the block's own rows of L staged in LDS, the tile's rows streamed from the factor: 0.5 MB
+        // per matrix in all), land in LDS as the block column, are eliminated there with the panels stacked under the
+        // diagonal block, and go home as final columns of L.  Nothing is left to update afterwards.
+        double *P = Lp;                             // P[j * pld + ii] = entry (kb + ii, kb + j) of the block column
+        double *Ak = Lp + NB * pld;                 // Ak[k * 16 + j] = L(kb + j, k), k < K
+        const int mi = lane & 15, mq = lane >> 4;
+        const bool has_cb = d.parent >= 0 && r > w;
+        // pivot blocks [kb, kb + bw) with K = kb pivots to their left, then -- the contribution block of a front that has
+        // one -- the remaining columns 16 at a time with all K = w pivots and no elimination
+        for (int kb = 0, ke = 0; kb < (has_cb ? r : w); kb = ke) {
+            const bool pivots = kb < w;
+            const int bw = pivots ? min(NB, w - kb) : min(NB, r - kb), nrow = r - kb;
+            ke = kb + bw;
+            const int nrem = r - ke;
+            const int K = pivots ? kb : w;
+            if (prof) t_mark = (long long) __builtin_amdgcn_s_memtime();
+            for (int e = tid; e < K * 16; e += 512) {
+                const int k = e >> 4, j = e & 15;
+                Ak[e] = load_if(F, (kb + j) + (long long) k * ld, j < bw);
+            }
+            __syncthreads();
+            const int nt = (nrow + 15) >> 4;
+            for (int t = wv; t < nt; t += 8) {
+                const int i = kb + 16 * t + mi;                 // my row: B operand and the outputs' lane & 15
+                const bool irow = i < r;
+                double4_t acc;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[v] = load_if(F, i + (long long) (kb + mq + 4 * v) * ld, irow && mq + 4 * v < bw);
+                const double *Frow = F + (irow ? i : 0);
+                for (int k0 = 0; k0 < K; k0 += 16) {            // sixteen pivots per pass: their operands first, then four MFMAs
+                    double au[4], bl[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = k0 + 4 * u + mq;
+                        const bool kin = k < K;
+                        au[u] = kin ? Ak[k * 16 + mi] : 0.0;
+                        bl[u] = Frow[(long long) (kin ? k : 0) * ld];
+                        bl[u] = (kin && irow) ? -bl[u] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(au[u], bl[u], acc, 0, 0, 0);
+                }
+                if (pivots) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        if (irow) P[(mq + 4 * v) * pld + 16 * t + mi] = acc[v];
+                } else {                                        // a block of the contribution block: final, in place
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        if (irow && mq + 4 * v < bw) F[i + (long long) (kb + mq + 4 * v) * ld] = acc[v];
+                }
+            }
+            __syncthreads();
+            if (prof) { const long long now = (long long) __builtin_amdgcn_s_memtime(); t_update += now - t_mark; t_mark = now; }
+            if (!pivots) continue;
+            // the block column: every wave eliminates the diagonal block with 32 of the rows below it stacked underneath
+            const int ng = max(1, (nrem + 31) / 32);
+            for (int t = wv; t < ng; t += 8) {
+                const int s0 = ke + 32 * t, si = s0 + li;
+                const bool owner = t == 0;
+                double e[NB];
+                if (!stacked) {
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const double v = P[j * pld + li];
+                        e[j] = (li < bw && j < bw) ? v : ((li == j) ? 1.0 : 0.0);
+                    }
+                } else {
+                    const bool mine = si < r;
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const double v = P[j * pld + (mine ? si - kb : 0)];
+                        e[j] = (mine && j < bw) ? v : 0.0;
+                    }
+                }
+                eliminate_block<KIND, NB>(e, false, bw);
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    if (j < bw) {
+                        const double v = e[j];
+                        if (!stacked) {
+                            if (owner && li < bw) {
+                                if ((li == j) & !(v > 0.0) && !bad) { bad = true; bad_col = kb + j; }
+                                if (li >= j) F[(kb + li) + (long long) (kb + j) * ld] = v;
+                            }
+                        } else if (si < r) {
+                            F[si + (long long) (kb + j) * ld] = v;
+                        }
+                    }
+                }
+            }
+            __syncthreads();                        // the columns are in the factor before the next block reads them
+            if (prof) t_panel += (long long) __builtin_amdgcn_s_memtime() - t_mark;
+        }
+    } else
     for (int kb = 0; kb < w; kb += NB) {
         const int bw = min(NB, w - kb), ke = kb + bw, nrem = r - ke;
         if (prof) t_mark = (long long) __builtin_amdgcn_s_memtime();
@@ -3504,7 +3604,9 @@ constexpr int WG_NB = 16;
 static int wg_nb() { return WG_NB; }
 static size_t wg_lds_bytes(int kind, const LaunchGroup &g)
 {
-    return ((size_t) wg_nb() * 33 + (size_t) (kind == CS3_LU ? 2 : 1) * wg_nb() * wg_panel_ld(g)) * sizeof(double);
+    // (Cholesky, left-looking: the block column + the block's own rows of the factor, 16 x max_w)
+    return ((size_t) wg_nb() * 33 + (size_t) (kind == CS3_LU ? 2 : 1) * wg_nb() * wg_panel_ld(g) +
+            (kind == CS3_LU ? 0 : (size_t) 16 * (size_t) g.max_w)) * sizeof(double);
 }
 bool big_group_in_one_workgroup(int kind, long long batch, const LaunchGroup &g)
 {

@@ -134,7 +134,7 @@ __device__ __forceinline__ void gather_front(long long asm_begin, int nchunks, i
 // additions to an entry is fixed, atomic or not -- what the instruction saves is the load, the wait and the store.
 __device__ __forceinline__ void front_add(double *p, double v) { unsafeAtomicAdd(p, v); }
 
-template <int KIND, class Put, class Acc, class Sync>
+template <int KIND, int EUB = 4, class Put, class Acc, class Sync>
 __device__ __forceinline__ void assemble_extend_add(const FrontDesc &d, const AsmLists &al, const double *__restrict__ ax,
                                                     const double *__restrict__ pool, const double *__restrict__ pil, long long il_len,
                                                     int tid, int nth, Put put, Acc acc, Sync sync)
@@ -179,6 +179,7 @@ __device__ __forceinline__ void assemble_extend_add(const FrontDesc &d, const As
             // lane has work whatever the block's order; e -> (row, column) by a float reciprocal and two corrections
             const int total = nbc * nbc;
             const float inv = 1.0f / (float) nbc;
+            constexpr int EU = EUB;                              // (a workgroup that assembles one big front by itself: 12)
             for (int e0 = tid; e0 < total; e0 += EU * nth) {
                 double v[EU];
                 int ri[EU], cj[EU];
@@ -1099,7 +1100,7 @@ k_front_wg(const FrontDesc *__restrict__ fdesc, int first,
     }
     __syncthreads();
     CS3_WSTAMP(0);
-    assemble_extend_add<KIND>(d, al, ax, pool, pil, il.len, tid, 512,
+    assemble_extend_add<KIND, 12>(d, al, ax, pool, pil, il.len, tid, 512,
                               [&](int t, double v) { pool[t] = v; },
                               [&](int i, int j, double v) { front_add(&F[i + (long long) j * ld], v); },
                               [&]() { __syncthreads(); });
@@ -1141,18 +1142,22 @@ k_front_wg(const FrontDesc *__restrict__ fdesc, int first,
 #pragma unroll
                 for (int v = 0; v < 4; ++v) acc[v] = load_if(F, i + (long long) (kb + mq + 4 * v) * ld, irow && mq + 4 * v < bw);
                 const double *Frow = F + (irow ? i : 0);
-                for (int k0 = 0; k0 < K; k0 += 16) {            // sixteen pivots per pass: their operands first, then four MFMAs
-                    double au[4], bl[4];
+                // 64 pivots per pass: the 16 operand loads of a lane go out together (the tile's rows of the factor come
+                // from L2 / HBM: with four loads per pass a late block column waited out 13 round trips per tile)
+                for (int k0 = 0; k0 < K; k0 += 64) {
+                    double bl[16];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < 16; ++u) {
                         const int k = k0 + 4 * u + mq;
-                        const bool kin = k < K;
-                        au[u] = kin ? Ak[k * 16 + mi] : 0.0;
-                        bl[u] = Frow[(long long) (kin ? k : 0) * ld];
-                        bl[u] = (kin && irow) ? -bl[u] : 0.0;
+                        bl[u] = Frow[(long long) (k < K ? k : 0) * ld];
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(au[u], bl[u], acc, 0, 0, 0);
+                    for (int u = 0; u < 16; ++u) {
+                        const int k = k0 + 4 * u + mq;
+                        const bool kin = k < K;
+                        if (k0 + 4 * u < K)                     // (wave-uniform)
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kin ? Ak[k * 16 + mi] : 0.0, (kin && irow) ? -bl[u] : 0.0, acc, 0, 0, 0);
+                    }
                 }
                 if (pivots) {
 #pragma unroll

@@ -146,8 +146,10 @@ __device__ __forceinline__ void assemble_extend_add(const FrontDesc &d, const As
     sync();
     const int lane = tid & 63;
     const int4 *tab = (const int4 *) al.ch_tab + d.ch_begin;
+    int4 ce_next = (d.ch_count > 0) ? tab[0] : int4{0, 0, 0, 0};
     for (int c = 0; c < d.ch_count; ++c) {
-        const int4 ce = tab[c];
+        const int4 ce = ce_next;
+        if (c + 1 < d.ch_count) ce_next = tab[c + 1];            // the next child's entry travels while this one is added
         const int nbc = ce.x, cbo = ce.z, cld = ce.w;
         const int *__restrict__ rel = al.rel_idx + ce.y;
         const bool il = cbo < il_len;                            // a block in the matrix-interleaved region (large batches)
@@ -1819,7 +1821,7 @@ k_fwd_rhs(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ s
     const int r = d.r, w = d.w;
     const double *L = pool + d.lpan;
     // the first rounds of slot indices: lane t holds the sources of row t (one round trip for up to SR rounds)
-    constexpr int SR = 4;
+    constexpr int SR = 8;
     const int rounds = d.rl_count, stride = (r + 15) & ~15;
     const int *sl = slots + d.rl_begin;
     int sidx[SR];

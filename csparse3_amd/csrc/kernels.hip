@@ -1821,7 +1821,7 @@ k_fwd_rhs(const SolveDesc *__restrict__ sd, int first, const int *__restrict__ s
     const int r = d.r, w = d.w;
     const double *L = pool + d.lpan;
     // the first rounds of slot indices: lane t holds the sources of row t (one round trip for up to SR rounds)
-    constexpr int SR = 8;
+    constexpr int SR = 4;
     const int rounds = d.rl_count, stride = (r + 15) & ~15;
     const int *sl = slots + d.rl_begin;
     int sidx[SR];

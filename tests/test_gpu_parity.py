@@ -991,3 +991,47 @@ def test_inverse_based_sweeps_hold_up_with_large_multipliers(gpu, diag_scale):
         assert np.abs(X[:, j] - X1[:, j]).max() <= 1e-9 * np.abs(X1[:, j]).max()
     for j in range(4, 32):
         assert res(X[:, j], B[:, j]) <= 1e-10
+
+
+@pytest.mark.parametrize("chol", [False, True])
+@pytest.mark.parametrize("nd", [20, 33, 40, 48, 64, 65, 81, 100, 136, 137, 180])
+@pytest.mark.parametrize("nb", [1, 20])
+def test_front_orders_across_the_kernel_classes(gpu, orc, chol, nd, nb):
+    """One embedded dense block of every order around the boundaries of the factor kernels -- one-wave / four-wave fronts
+    with the panel + MFMA Schur complement (<= 32 pivots), the 16 x 16 thread grid (33..64 pivots), the LDS-resident block
+    kernel with its equal-width blocks (65..136), the blocked big-front path (> 136) -- single and batched (the batched
+    handle takes the one-wave kernel, two-wave fronts and, for Cholesky, the packed images): L and U against the oracle
+    entry for entry, residuals, and run-to-run bits."""
+    import scipy.sparse as sp
+    m, n, Ap, Ai, Ax = synth.dense_block_matrix(n=nd + 120, nd=nd, seed=1000 + nd)
+    kind = gpu.CS3_LU
+    if chol:
+        A = sp.csc_matrix((Ax, Ai, Ap), shape=(n, n))
+        S = (A + A.T).tocsc(); S.sort_indices()
+        Ap, Ai, Ax = S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.copy()
+        kind = gpu.CS3_CHOLESKY
+    rng = np.random.default_rng(nd + nb)
+    AX = Ax[None, :] * (1.0 + rng.uniform(0.0, 0.5, size=(nb, 1)))
+    B = rng.standard_normal((nb, n, 3))
+    tol = 0.0 if chol else 1e-3
+    with gpu.Factorization(m, n, Ap, Ai, kind=kind, batch=nb) as F:
+        assert F.info.max_front >= nd
+        F.factor(AX if nb > 1 else AX[0], tol)
+        X = F.solve(B if nb > 1 else B[0])
+        q = F.ordering()["q"]
+        picks = sorted({0, nb - 1})
+        facs = {i: (F.factors(b=i) if nb > 1 else F.factors()) for i in picks}
+        F.factor(AX if nb > 1 else AX[0], tol)
+        assert np.array_equal(F.solve(B if nb > 1 else B[0]), X)
+    X = X if nb > 1 else X[None]
+    for i, (Lp, Li, Lx, Up, Ui, Ux) in facs.items():
+        what = "order %d, %s, matrix %d of %d" % (nd, "chol" if chol else "lu", i, nb)
+        if chol:
+            assert_factor_equal(n, (Lp, Li, Lx), _oracle_chol(orc, n, Ap, Ai, AX[i], q), what)
+        else:
+            oL = orc.csc_lu_f(n, n, Ap, Ai, AX[i], q, 1e-3)
+            assert_factor_equal(n, (Lp, Li, Lx), oL[0:3], what + " L")
+            assert_factor_equal(n, (Up, Ui, Ux), oL[3:6], what + " U")
+    for i in range(nb):
+        A = csc_to_scipy(m, n, Ap, Ai, AX[i])
+        assert np.abs(A @ X[i] - B[i]).max() <= 1e-11 * n * max(1.0, np.abs(X[i]).max())

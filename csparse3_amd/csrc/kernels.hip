@@ -178,9 +178,13 @@ __device__ __forceinline__ void assemble_extend_add(const FrontDesc &d, const As
             }
         } else {
             // the block's entries dealt to the threads one after the other (rows fastest: coalesced), so that every
-            // lane has work whatever the block's order; e -> (row, column) by a float reciprocal and two corrections
-            const int total = nbc * nbc;
+            // lane has work whatever the block's order; e -> (row, column) by a float reciprocal and two corrections.
+            // Cholesky walks the LOWER TRIANGLE only (packed by columns: column j starts at j (2 n - j + 1) / 2; the column
+            // of an entry from a float square root and two corrections -- exact: the discriminant stays below 2^24): a
+            // walk over the whole square issued a dummy load for every entry above the diagonal, half of all passes.
+            const int total = (KIND == CS3_LU) ? nbc * nbc : (nbc * (nbc + 1)) >> 1;
             const float inv = 1.0f / (float) nbc;
+            const float twon1 = (float) (2 * nbc + 1);
             constexpr int EU = EUB;                              // (a workgroup that assembles one big front by itself: 12)
             for (int e0 = tid; e0 < total; e0 += EU * nth) {
                 double v[EU];
@@ -189,11 +193,21 @@ __device__ __forceinline__ void assemble_extend_add(const FrontDesc &d, const As
 #pragma unroll
                 for (int u = 0; u < EU; ++u) {
                     const int e = e0 + u * nth;
-                    int jj = (int) ((float) e * inv);
-                    jj += ((jj + 1) * nbc <= e) ? 1 : 0;
-                    jj -= (jj * nbc > e) ? 1 : 0;
-                    const int ii = e - jj * nbc;
-                    on[u] = e < total && (KIND == CS3_LU || ii >= jj);
+                    int ii, jj;
+                    if (KIND == CS3_LU) {
+                        jj = (int) ((float) e * inv);
+                        jj += ((jj + 1) * nbc <= e) ? 1 : 0;
+                        jj -= (jj * nbc > e) ? 1 : 0;
+                        ii = e - jj * nbc;
+                    } else {
+                        const int ec = min(e, total - 1);
+                        jj = (int) ((twon1 - sqrtf(twon1 * twon1 - 8.0f * (float) ec)) * 0.5f);
+                        jj = min(max(jj, 0), nbc - 1);
+                        while ((((jj + 1) * (2 * nbc - jj)) >> 1) <= ec) ++jj;             // (start of column jj + 1)
+                        while (((jj * (2 * nbc - jj + 1)) >> 1) > ec) --jj;                 // (start of column jj)
+                        ii = jj + (ec - ((jj * (2 * nbc - jj + 1)) >> 1));
+                    }
+                    on[u] = e < total;
                     const long long off = on[u] ? cbo + ii + (long long) jj * cld : cbo;
                     v[u] = il ? pil[off * 64] : pool[off];
                     ri[u] = rel[on[u] ? ii : 0];

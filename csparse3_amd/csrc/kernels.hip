@@ -2624,10 +2624,15 @@ k_front_il(const FrontDesc *__restrict__ fdesc, int first, const int *__restrict
         const int *pr = pairs + 2 * d.a_begin;
         int cur = -1;
         double acc = 0.0;
+        int ptg_n = pr[2 * (lane < min(64, np) ? lane : 0)], psr_n = pr[2 * (lane < min(64, np) ? lane : 0) + 1];
         for (int base = 0; base < np; base += 64) {
             const int have = min(64, np - base);
-            const int e = base + (lane < have ? lane : 0);
-            const int ptg = pr[2 * e], psr = pr[2 * e + 1];                   // pair `lane` of this block of 64
+            const int ptg = ptg_n, psr = psr_n;                               // pair `lane` of this block of 64
+            if (base + 64 < np) {                                             // the next block's pairs travel meanwhile
+                const int have_n = min(64, np - base - 64);
+                const int e_n = base + 64 + (lane < have_n ? lane : 0);
+                ptg_n = pr[2 * e_n]; psr_n = pr[2 * e_n + 1];
+            }
             for (int c = 0; c < have; c += IL_AV) {              // `have` is a multiple of 16: the tail of a block reads pair 0
                 double val[IL_AV];
 #pragma unroll

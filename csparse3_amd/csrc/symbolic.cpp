@@ -635,7 +635,9 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     auto order_r = [&](i32 s) -> i64 { return S.st_ptr[s + 1] - S.st_ptr[s]; };
     i64 voff = 0, cvoff = 0;
     S.max_front = 0; S.max_width = 0; S.flops = 0.0;
-    i64 il_min_batch = 64;
+    // (round 3: with the matrix-core Schur complements the lane = row kernels win below ~ 130 matrices -- 64 matrices 0.83 against
+    //  0.92 ms, 128 equal, 192 matrices 1.54 against 1.42 -- the threshold was 64 in round 2)
+    i64 il_min_batch = 128;
     if (const char *e = std::getenv("CS3_IL_MIN_BATCH")) il_min_batch = std::atoll(e);
     const bool interleave = S.batch >= il_min_batch;
     for (i32 s = 0; s < ns; ++s) {                   // interleaved region first: dense r x r buffers of the FC_IL fronts

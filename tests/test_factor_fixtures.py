@@ -147,12 +147,12 @@ def test_hip_toy10_known_answer(gpu):
 
 
 @pytest.mark.gpu
-def test_hip_batch_of_the_fixture_matrix(gpu):
-    """Config 2 as a batch of 70 scaled copies (more than one 64-matrix group): every factor and solution is
-    the scaled fixture answer."""
+@pytest.mark.parametrize("nb", [70, 130])
+def test_hip_batch_of_the_fixture_matrix(gpu, nb):
+    """Config 2 as a batch of 70 / 130 scaled copies (more than one 64-matrix group; 130: the lane = matrix kernels, which
+    take the small fronts from 128 matrices on): every factor and solution is the scaled fixture answer."""
     n, g = _get("config2")
     Ap, Ai, Ax, b = g("Ap"), g("Ai"), g("Ax"), g("b")
-    nb = 70
     scale = 1.0 + np.arange(nb) / 7.0
     AX = Ax[None, :] * scale[:, None]
     B = np.repeat(b[None, :, None], nb, axis=0)

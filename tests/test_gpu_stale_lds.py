@@ -73,7 +73,7 @@ def test_numeric_entry_points_with_poisoned_lds(gpu, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nmat", [6, 70])
+@pytest.mark.parametrize("nmat", [6, 70, 130])      # (130: the lane = matrix kernels, from 128 matrices on)
 @pytest.mark.parametrize("chol", [False, True])
 def test_batches_with_poisoned_lds(gpu, nmat, chol):
     n = 1200

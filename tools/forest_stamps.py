@@ -38,7 +38,7 @@ for t in range(int(tier[:nf].max()) + 1):
     for l in range(int(lvl[mine].max()) + 1):
         fl = mine[lvl[mine] == l]
         j = fl[np.argmax(st[fl, 5])]
-        if w[sn[j]] >= int(os.environ.get("CS3_SUB_COOP_W", "6")):      # shared by four waves: stamps per part
+        if w[sn[j]] >= 6:      # (ForestLimits::coop_w) shared by four waves: stamps per part
             print("  level %2d fronts %3d  shared r,w,children = %2d,%2d,%2d  start %7d | part 0 stored %7d | parts 1-3 (assembled, eliminated): %s" % (
                 l, len(fl), r[sn[j]], w[sn[j]], nch[sn[j]], st[j, 0], st[j, 1], " ".join("(%d, %d)" % (st[j, 2 * q], st[j, 2 * q + 1]) for q in (1, 2, 3))))
             continue

@@ -925,6 +925,17 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
     }
     tick("10. launch groups");
     // ---- 10b. forward-solve gather lists and the solve schedule
+    // (items of a front sorted by target, stable: a counting sort over the front's rows -- targets are row numbers < r)
+    std::vector<i32> cs_count;
+    std::vector<Item> cs_out;
+    auto sort_by_row = [&](std::vector<Item> &items, i64 r) {
+        cs_count.assign((size_t) r + 1, 0);
+        for (const Item &it : items) ++cs_count[(size_t) it.tgt + 1];
+        for (i64 t = 0; t < r; ++t) cs_count[(size_t) t + 1] += cs_count[(size_t) t];
+        cs_out.resize(items.size());
+        for (const Item &it : items) cs_out[(size_t) cs_count[(size_t) it.tgt]++] = it;
+        items.swap(cs_out);
+    };
     S.fasm_ptr.assign(ns + 1, 0);
     S.fasm_src.clear(); S.fasm_tgt.clear(); S.flong_src.clear();
     {
@@ -939,7 +950,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
                 const i32 *rel = S.rel_idx.data() + S.rel_ptr[c];
                 for (i64 ii = 0; ii < nbc; ++ii) items.push_back(Item{rel[ii], (i32) (S.cv_off[c] + ii)});
             }
-            std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.tgt < b.tgt; });
+            sort_by_row(items, order_r(s));
             emit_runs(items, S.fasm_tgt, S.fasm_src, S.flong_src);
             S.fasm_ptr[s + 1] = (i64) S.fasm_tgt.size();
         }
@@ -982,7 +993,7 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
                 const i32 *rel = S.rel_idx.data() + S.rel_ptr[c];
                 for (i64 ii = 0; ii < nbc; ++ii) items.push_back(Item{rel[ii], (i32) (S.cv_off[c] + ii)});
             }
-            std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.tgt < b.tgt; });
+            sort_by_row(items, order_r(s));
             if (sk == SK_IL) {
                 for (const Item &it : items) { S.rl_pairs.push_back(it.tgt); S.rl_pairs.push_back(it.src); }
                 while ((S.rl_pairs.size() / 2) % 16) { S.rl_pairs.push_back(-1); S.rl_pairs.push_back(0); }

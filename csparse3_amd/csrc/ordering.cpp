@@ -68,15 +68,17 @@ public:
 private:
     i64 n_;
     i64 used_;                       // G[0 .. used_) holds live lists
-    std::vector<i64> G_;             // adjacency memory: per object, elements first then variables
-    std::vector<i64> at_;            // start of object's list; flip(parent) once absorbed; -1 root
-    std::vector<i64> len_;           // list length
-    std::vector<i64> elen_;          // #elements in a variable's list; -2 element; -1 dead variable
-    std::vector<i64> size_;          // supervariable size (negated while in the current Lk)
-    std::vector<i64> deg_;           // approximate external degree
-    std::vector<i64> tag_;           // scratch marks; 0 = dead element
-    std::vector<i64> bucket_, fwd_, back_;   // degree lists
-    std::vector<i64> hash_;          // hash buckets
+    // (32-bit storage since round 3: half the cache footprint of the quotient graph; every value is an index, a count or a
+    //  tag below 2^31 -- reset_tags restarts the tags before they can pass it -- and the arithmetic on them stays 64-bit)
+    std::vector<i32> G_;             // adjacency memory: per object, elements first then variables
+    std::vector<i32> at_;            // start of object's list; flip(parent) once absorbed; -1 root
+    std::vector<i32> len_;           // list length
+    std::vector<i32> elen_;          // #elements in a variable's list; -2 element; -1 dead variable
+    std::vector<i32> size_;          // supervariable size (negated while in the current Lk)
+    std::vector<i32> deg_;           // approximate external degree
+    std::vector<i32> tag_;           // scratch marks; 0 = dead element
+    std::vector<i32> bucket_, fwd_, back_;   // degree lists
+    std::vector<i32> hash_;          // hash buckets
     i64 mark_ = 0, lemax_ = 0, mindeg_ = 0, done_ = 0;
 
     void reset_tags(i64 advance);
@@ -120,7 +122,7 @@ QuotientGraph::QuotientGraph(i64 n, const std::vector<i64> &Cp, const std::vecto
 void QuotientGraph::reset_tags(i64 advance)
 {
     mark_ += advance;
-    if (mark_ < 2 || mark_ + lemax_ < 0) {
+    if (mark_ < 2 || mark_ + lemax_ < 0 || mark_ + lemax_ > 2147483000LL) {
         for (i64 k = 0; k < n_; ++k) if (tag_[k] != 0) tag_[k] = 1;
         mark_ = 2;
     }
@@ -172,7 +174,7 @@ void QuotientGraph::eliminate_all()
 
 void QuotientGraph::eliminate(i64 k)
 {
-    std::vector<i64> &G = G_;
+    std::vector<i32> &G = G_;
     const i64 ek = elen_[k];
     i64 nvk = size_[k];
     done_ += nvk;
@@ -251,7 +253,7 @@ void QuotientGraph::eliminate(i64 k)
             size_[i] = 0;
             elen_[i] = -1;
         } else {
-            deg_[i] = std::min(deg_[i], d);
+            deg_[i] = (i32) std::min<i64>(deg_[i], d);
             G[out] = G[p3];
             G[p3] = G[p1];
             G[p1] = k;

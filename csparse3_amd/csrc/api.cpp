@@ -538,7 +538,8 @@ int cs3_amd(int64_t order, int64_t m, int64_t n, const int32_t *Ap, const int32_
     try {
         if (order == CS3_ORDER_NATURAL) { for (int64_t k = 0; k < n; ++k) q[k] = (int32_t) k; return CS3_OK; }
         if (order != CS3_ORDER_AMD) { set_error("cs3_amd: order must be 0 or 1"); return CS3_ERR_ARG; }
-        std::vector<i64> Cp, Ci;
+        std::vector<i64> Cp;
+        std::vector<i32> Ci;
         symmetrized_pattern(n, Ap, Ai, Cp, Ci);
         std::vector<i32> perm;
         amd_order(n, Cp, Ci, perm);

@@ -18,9 +18,9 @@ void set_error(const std::string &msg);
 // Pattern of A + A' without the diagonal; column j lists A(:,j) in A's order
 // followed by the entries of A'(:,j) that A(:,j) lacks (A' has sorted columns).
 void symmetrized_pattern(i64 n, const i32 *Ap, const i32 *Ai,
-                         std::vector<i64> &Cp, std::vector<i64> &Ci);
+                         std::vector<i64> &Cp, std::vector<i32> &Ci);
 // Approximate minimum degree on that pattern.
-void amd_order(i64 n, const std::vector<i64> &Cp, const std::vector<i64> &Ci,
+void amd_order(i64 n, const std::vector<i64> &Cp, const std::vector<i32> &Ci,
                std::vector<i32> &perm);
 
 // ---- symbolic.cpp --------------------------------------------------------

@@ -25,31 +25,32 @@
 namespace cs3 {
 
 void symmetrized_pattern(i64 n, const i32 *Ap, const i32 *Ai,
-                         std::vector<i64> &Cp, std::vector<i64> &Ci)
+                         std::vector<i64> &Cp, std::vector<i32> &Ci)
 {
     // transpose (rows of A' come out sorted)
-    std::vector<i64> Tp(n + 1, 0), Ti(Ap[n]);
+    std::vector<i64> Tp(n + 1, 0);
+    std::vector<i32> Ti(Ap[n]);
     for (i64 p = 0; p < Ap[n]; ++p) ++Tp[Ai[p] + 1];
     for (i64 j = 0; j < n; ++j) Tp[j + 1] += Tp[j];
     {
         std::vector<i64> fill(Tp.begin(), Tp.end() - 1);
         for (i64 j = 0; j < n; ++j)
-            for (i64 p = Ap[j]; p < Ap[j + 1]; ++p) Ti[fill[Ai[p]]++] = j;
+            for (i64 p = Ap[j]; p < Ap[j + 1]; ++p) Ti[fill[Ai[p]]++] = (i32) j;
     }
     Cp.assign(n + 1, 0);
     Ci.clear();
     Ci.reserve(2 * (size_t) Ap[n]);
-    std::vector<i64> seen(n, -1);
+    std::vector<i32> seen(n, -1);
     for (i64 j = 0; j < n; ++j) {
         Cp[j] = (i64) Ci.size();
-        seen[j] = j;                                    // never list the diagonal
+        seen[j] = (i32) j;                                    // never list the diagonal
         for (i64 p = Ap[j]; p < Ap[j + 1]; ++p) {
             i64 i = Ai[p];
-            if (seen[i] != j) { seen[i] = j; Ci.push_back(i); }
+            if (seen[i] != j) { seen[i] = (i32) j; Ci.push_back((i32) i); }
         }
         for (i64 p = Tp[j]; p < Tp[j + 1]; ++p) {
             i64 i = Ti[p];
-            if (seen[i] != j) { seen[i] = j; Ci.push_back(i); }
+            if (seen[i] != j) { seen[i] = (i32) j; Ci.push_back((i32) i); }
         }
     }
     Cp[n] = (i64) Ci.size();
@@ -61,7 +62,7 @@ inline i64 flip(i64 i) { return -i - 2; }
 
 class QuotientGraph {
 public:
-    QuotientGraph(i64 n, const std::vector<i64> &Cp, const std::vector<i64> &Ci);
+    QuotientGraph(i64 n, const std::vector<i64> &Cp, const std::vector<i32> &Ci);
     void eliminate_all();
     void assembly_postorder(std::vector<i32> &perm);
 
@@ -88,7 +89,7 @@ private:
     void eliminate(i64 k);
 };
 
-QuotientGraph::QuotientGraph(i64 n, const std::vector<i64> &Cp, const std::vector<i64> &Ci)
+QuotientGraph::QuotientGraph(i64 n, const std::vector<i64> &Cp, const std::vector<i32> &Ci)
     : n_(n), used_(Cp[n]), G_(Cp[n] + Cp[n] / 5 + 2 * n), at_(Cp.begin(), Cp.end()),
       len_(n + 1), elen_(n + 1, 0), size_(n + 1, 1), deg_(n + 1), tag_(n + 1, 1),
       bucket_(n + 1, -1), fwd_(n + 1, -1), back_(n + 1, -1), hash_(n + 1, -1)
@@ -353,7 +354,7 @@ void QuotientGraph::assembly_postorder(std::vector<i32> &perm)
 
 }  // namespace
 
-void amd_order(i64 n, const std::vector<i64> &Cp, const std::vector<i64> &Ci,
+void amd_order(i64 n, const std::vector<i64> &Cp, const std::vector<i32> &Ci,
                std::vector<i32> &perm)
 {
     if (n == 0) { perm.clear(); return; }

@@ -349,7 +349,8 @@ void analyze(int kind, int order, i64 n, const i32 *Ap, const i32 *Ai,
 
     // ---- 1. fill-reducing order on the pattern of A + A'
     auto t0 = std::chrono::steady_clock::now();
-    std::vector<i64> Cp, Ci;
+    std::vector<i64> Cp;
+    std::vector<i32> Ci;
     symmetrized_pattern(n, Ap, Ai, Cp, Ci);
     S.q_amd.resize(n);
     if (order == CS3_ORDER_NATURAL) {

@@ -16,7 +16,7 @@ for case in range(ncase):
     nd = int(rng.choice([0, 40, 65, 97, 129, 160, 200, 257, 330, 449, 520]))
     n = nd + int(rng.integers(50, 900))
     nrhs = int(rng.choice([1, 2, 7, 8, 9, 15, 16, 17, 33, 64, 70, 128, 256, 300]))
-    chol = bool(rng.integers(0, 2)); batch = int(rng.choice([1, 1, 1, 3, 16, 64, 70]))
+    chol = bool(rng.integers(0, 2)); batch = int(rng.choice([1, 1, 1, 3, 16, 64, 70, 130]))     # (130: the lane = matrix kernels, from 128 matrices on)
     if batch >= 16: nrhs = min(nrhs, 70)          # (memory: batch x n x nrhs doubles, three copies)
     if nd:
         m, n, Ap, Ai, Ax = synth.dense_block_matrix(n=n, nd=nd, seed=int(rng.integers(1 << 30)))
